@@ -1,0 +1,139 @@
+/*
+ * tfa.h — C ABI of the MI355X (gfx950) FlashAttention-2 forward path.
+ *
+ * This is the drop-in boundary for the ONE hot path of 66RING/tiny-flash-attention:
+ * the fused  S = scale * Q K^T  ->  online softmax  ->  O = P V  forward tile loop.
+ * Everything here is `extern "C"`, plain pointers and sizes; no torch types.
+ * Pointers are DEVICE pointers (HBM) unless stated otherwise.  The library never
+ * allocates or frees device memory and keeps no state between calls except the
+ * debug knob tfa_set_variant().
+ *
+ * Reference interfaces each entry point replaces (paths relative to the reference repo):
+ *
+ *   tfa_fwd_bhnd      <- flash_attention_v2_cutlass(q,k,v,is_causal,softmax_scale) -> {out, lse}
+ *                        flash_attention_cutlass/csrc/flash_attention.cu:741-772
+ *                        (declared flash_attention_cutlass/include/attention_api.h:10-11,
+ *                         bound   flash_attention_cutlass/csrc/attention_api.cpp:6-10)
+ *                     <- flash_attention_v2_cuda(q,k,v) -> out      [scale=1/sqrt(D), non causal]
+ *                        flash_attention_cuda/csrc/flash_attention.cu:375-424
+ *                     <- _kernels.flash_attn(q,k,v,is_causal,softmax_scale) -> out   [CPU sibling]
+ *                        flash_attention_c/csrc/attn.cpp:237-262
+ *   tfa_fwd           <- set_params_fprop + run_flash_attn_cutlass (strided / GQA / Nq!=Nk general form)
+ *                        flash_attention_cutlass/csrc/flash_attention.cu:320-361, 731-739
+ *                        flash_attention_cutlass/csrc/flash.h:6-59   (Flash_fwd_params)
+ *                        flash_attention_c/csrc/attn.cpp:171-203     (strided params, causal offset)
+ *   tfa_strerror      <- CUDA_ERROR_CHECK / TORCH_CHECK text
+ *                        flash_attention_cutlass/include/attention_api.cuh:12-29
+ *
+ * Semantics (identical to the reference; see oracle/ for the CPU restatement):
+ *   S[i,j]  = softmax_scale * sum_d q[i,d] k[j,d]            (16-bit products, fp32 accumulate)
+ *   causal:   S[i,j] = -inf for j > i + (Nk - Nq)            (attn.cpp:122-124)
+ *   m_i = max_j S ; P = exp(S - m_i) ; l_i = sum_j P         (fp32)
+ *   O[i,:]  = (sum_j round16(P[i,j]) v[j,:]) / l_i           (P rounded to the input dtype before PV,
+ *                                                             flash_attention.cu:601; l sums unrounded P)
+ *   O -> rounded to the input dtype (RNE), or left fp32 when out_dtype == TFA_F32
+ *   LSE_i   = m_i + ln(l_i)   (natural log, scale included)  (flash_attention.cu:623)
+ *   empty row (no visible key): O = 0, LSE = +inf            (flash_attention.cu:620-623)
+ *
+ * Error convention: every entry point returns 0 on success, a negative tfa_status on a
+ * rejected argument (nothing was launched), or a positive hipError_t when the HIP runtime
+ * reported an error on launch.  No entry point synchronises the device or calls exit()
+ * (the reference does both, flash_attention.cu:767-769; callers already synchronise).
+ */
+#ifndef TFA_H_
+#define TFA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFA_VERSION 100 /* 0.1.0 */
+
+/* element types */
+enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1, TFA_F32 = 2 /* output only */ };
+
+enum tfa_status {
+  TFA_OK = 0,
+  TFA_ERR_NULL = -1,          /* a required pointer is NULL */
+  TFA_ERR_DTYPE = -2,         /* dtype not in {F16,BF16}; out_dtype not in {dtype,F32} */
+  TFA_ERR_HEAD_DIM = -3,      /* D not in {64,128} */
+  TFA_ERR_SHAPE = -4,         /* B,H,Hk,Nq,Nk <= 0 or H % Hk != 0 */
+  TFA_ERR_STRIDE = -5,        /* a stride is negative, not 16-byte aligned, or a slice exceeds 4 GiB */
+  TFA_ERR_ALIGN = -6,         /* a base pointer is not 16-byte aligned */
+  TFA_ERR_VARIANT = -7,       /* unknown kernel variant */
+  TFA_ERR_SCALE = -8          /* softmax_scale is not finite or is <= 0 */
+};
+
+/*
+ * General problem descriptor.  Tensors are 4-D logical (B, H, N, D) with arbitrary
+ * batch/head/row strides (in ELEMENTS) and unit stride along D, so both the reference's
+ * contiguous (B,H,N,D) layout and the (B,N,H,D) layout of flash_attn_func are expressible.
+ * K and V have Hk heads (Hk divides H; Hk == H for plain MHA; query head h reads kv head
+ * h / (H/Hk), the grouping of flash_attention_c/csrc/archive_)/attn.cpp:61).
+ */
+typedef struct tfa_fwd_params {
+  const void* q;  /* (B,H ,Nq,D) */
+  const void* k;  /* (B,Hk,Nk,D) */
+  const void* v;  /* (B,Hk,Nk,D) */
+  void* out;      /* (B,H ,Nq,D) of out_dtype */
+  float* lse;     /* (B,H,Nq) fp32 contiguous, or NULL to skip */
+  int32_t B, H, Hk, Nq, Nk, D;
+  int64_t q_stride[3];   /* batch, head, row (elements) */
+  int64_t k_stride[3];
+  int64_t v_stride[3];
+  int64_t o_stride[3];   /* in elements of out_dtype */
+  float softmax_scale;
+  int32_t is_causal;     /* bottom-right aligned when Nq != Nk */
+  int32_t dtype;         /* tfa_dtype of q,k,v: TFA_F16 or TFA_BF16 */
+  int32_t out_dtype;     /* == dtype, or TFA_F32 (debug/parity: unrounded fp32 O) */
+} tfa_fwd_params;
+
+/* Library version (TFA_VERSION of the build). */
+int tfa_version(void);
+
+/* Human-readable text for a return code of any entry point (static storage). */
+const char* tfa_strerror(int status);
+
+/* Launch the forward pass described by *p on HIP stream `stream` (NULL = default stream).
+ * Asynchronous: returns after enqueueing. */
+int tfa_fwd(const tfa_fwd_params* p, void* stream);
+
+/* Convenience form for the reference's layout: q,k,v,out contiguous (B,H,N,D), Nq == Nk == N,
+ * Hk == H, out dtype == input dtype.  This is exactly the argument list of
+ * flash_attention_v2_cutlass (flash_attention.cu:741-742) plus explicit sizes. */
+int tfa_fwd_bhnd(const void* q, const void* k, const void* v, void* out, float* lse,
+                 int B, int H, int N, int D, float softmax_scale, int is_causal,
+                 int dtype, void* stream);
+
+/* Same, but O is written as fp32 (no final rounding) — the debug path used to check the
+ * rtol=1e-3 parity target below one bf16 ulp (precedent: FPC_O=float,
+ * flash_attention_cutlass/standalone_src/flash_attention_cutlass_standalone.cu:18-23). */
+int tfa_fwd_bhnd_f32out(const void* q, const void* k, const void* v, float* out, float* lse,
+                        int B, int H, int N, int D, float softmax_scale, int is_causal,
+                        int dtype, void* stream);
+
+/* Validate *p without launching; on success optionally reports the launch geometry. */
+int tfa_fwd_plan(const tfa_fwd_params* p, int* grid, int* block, int* lds_bytes);
+
+/* Time `iters` back-to-back launches of *p with HIP events recorded on `stream`
+ * (after `warmup` untimed launches).  Writes the average milliseconds per launch.
+ * Synchronises `stream`.  Used by bench.py for the roofline numbers. */
+int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, float* avg_ms);
+
+/* Kernel-variant selector for A/B measurement and bring-up.  -1 = automatic (default).
+ * tfa_num_variants() variants exist; tfa_variant_name(i) describes variant i. */
+int tfa_set_variant(int variant);
+int tfa_get_variant(void);
+int tfa_num_variants(void);
+const char* tfa_variant_name(int variant);
+
+/* Algorithmic work of *p: flops = 4*B*H*Nq*Nk*D (x1/2 when causal, the reference's
+ * convention) and bytes = Q+K+V read once + O written once (+LSE). */
+int tfa_fwd_work(const tfa_fwd_params* p, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFA_H_ */

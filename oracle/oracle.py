@@ -1,0 +1,197 @@
+"""oracle/oracle.py — Python face of the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (tiny-flash-attention_amd/) never does.
+
+Three layers, all CPU:
+  * C restatement (oracle/ref_attn.c via ctypes): ``naive``, ``online`` (fp32, following
+    flash_attention_c/csrc/attn.cpp:35-98 and :101-169) and ``exact64`` (fp64 ground truth of
+    the GPU contract incl. 16-bit P rounding, flash_attention.cu:263-316,601,608-630).
+  * ``tiled_emulation``: restatement of the reference's torch tile loop
+    (flash_attention_py/main_torch_only.py:160-270): block_m x block_n tiles, causal mask,
+    scale, P cast to the input dtype before PV.
+  * ``ref_kernels()``: the reference's OWN compiled CPU path (oracle/_ref/_kernels*.so, built
+    unmodified from /root/reference by oracle/Makefile) when present.
+"""
+import ctypes as C
+import glob
+import importlib.util
+import math
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+class _Args(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+        ("B", C.c_int), ("H", C.c_int), ("Hk", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("D", C.c_int),
+        ("qs", C.c_int64 * 3), ("ks", C.c_int64 * 3), ("vs", C.c_int64 * 3), ("os", C.c_int64 * 3),
+        ("scale", C.c_float), ("causal", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        for name in ("oracle_attn_naive", "oracle_attn_online"):
+            getattr(L, name).restype = C.c_int
+            getattr(L, name).argtypes = [C.POINTER(_Args)]
+        L.oracle_attn_exact64.restype = C.c_int
+        L.oracle_attn_exact64.argtypes = [C.POINTER(_Args), C.c_int]
+        L.oracle_round_bf16.restype = C.c_float
+        L.oracle_round_bf16.argtypes = [C.c_float]
+        L.oracle_round_fp16.restype = C.c_float
+        L.oracle_round_fp16.argtypes = [C.c_float]
+        L.oracle_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def num_threads():
+    return lib().oracle_num_threads()
+
+
+_P_ROUND = {None: 0, "none": 0, torch.float32: 0, torch.bfloat16: 1, "bf16": 1, torch.float16: 2, "fp16": 2}
+
+
+def _run(kind, q, k, v, is_causal, softmax_scale, p_round=None, return_lse=False):
+    """q (B,H,Nq,D), k/v (B,Hk,Nk,D): CPU tensors of any float dtype (upcast to fp32 exactly)."""
+    q32 = q.detach().to("cpu", torch.float32).contiguous()
+    k32 = k.detach().to("cpu", torch.float32).contiguous()
+    v32 = v.detach().to("cpu", torch.float32).contiguous()
+    B, H, Nq, D = q32.shape
+    _, Hk, Nk, _ = k32.shape
+    out = torch.empty_like(q32)
+    lse = torch.empty((B, H, Nq), dtype=torch.float32)
+    a = _Args()
+    a.q, a.k, a.v, a.o, a.lse = q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), out.data_ptr(), lse.data_ptr()
+    a.B, a.H, a.Hk, a.Nq, a.Nk, a.D = B, H, Hk, Nq, Nk, D
+    for name, t in (("qs", q32), ("ks", k32), ("vs", v32), ("os", out)):
+        arr = getattr(a, name)
+        arr[0], arr[1], arr[2] = t.stride(0), t.stride(1), t.stride(2)
+    a.scale = float(softmax_scale)
+    a.causal = 1 if is_causal else 0
+    if kind == "naive":
+        rc = lib().oracle_attn_naive(C.byref(a))
+    elif kind == "online":
+        rc = lib().oracle_attn_online(C.byref(a))
+    else:
+        rc = lib().oracle_attn_exact64(C.byref(a), _P_ROUND[p_round])
+    assert rc == 0
+    return (out, lse) if return_lse else out
+
+
+def naive_attn(q, k, v, is_causal, softmax_scale, return_lse=False):
+    """C restatement of run_naive_attn (flash_attention_c/csrc/attn.cpp:35-98)."""
+    return _run("naive", q, k, v, is_causal, softmax_scale, return_lse=return_lse)
+
+
+def flash_attn(q, k, v, is_causal, softmax_scale, return_lse=False):
+    """C restatement of run_flash_attn (flash_attention_c/csrc/attn.cpp:101-169)."""
+    return _run("online", q, k, v, is_causal, softmax_scale, return_lse=return_lse)
+
+
+def exact64(q, k, v, is_causal, softmax_scale, p_round=None, return_lse=False):
+    """fp64 ground truth; ``p_round`` in {None, torch.bfloat16, torch.float16} rounds P before PV."""
+    return _run("exact64", q, k, v, is_causal, softmax_scale, p_round=p_round, return_lse=return_lse)
+
+
+def sdpa_reference(q, k, v, is_causal, softmax_scale):
+    """torch fp32 reference of the same op (the comparison the reference's scripts use,
+    flash_attention_c/test.py:9-19, flash_attention_cutlass/test.py:19-27): softmax in fp32."""
+    q32, k32, v32 = (t.detach().to("cpu", torch.float32) for t in (q, k, v))
+    if k32.shape[1] != q32.shape[1]:
+        rep = q32.shape[1] // k32.shape[1]
+        k32 = k32.repeat_interleave(rep, dim=1)
+        v32 = v32.repeat_interleave(rep, dim=1)
+    p = torch.matmul(q32, k32.transpose(2, 3)) * softmax_scale
+    nq, nk = q32.shape[-2], k32.shape[-2]
+    if is_causal:
+        i = torch.arange(nq)[:, None]
+        j = torch.arange(nk)[None, :]
+        p = p.masked_fill(j > i + (nk - nq), float("-inf"))
+    lse = torch.logsumexp(p, dim=-1)
+    p = torch.softmax(p, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)  # empty rows
+    return torch.matmul(p, v32), lse
+
+
+def tiled_emulation(q, k, v, is_causal, softmax_scale, block_m=32, block_n=64):
+    """Restatement of flash_attention_v2 in flash_attention_py/main_torch_only.py:160-270 for
+    (B,H,N,D) inputs: Q-outer / KV-inner tile loop, causal mask per tile (:231-237), scale (:239),
+    running max/sum (:240-257), ``local_score.to(q.dtype) @ v_tile`` (:260), final divide (:267).
+    Returns fp32 (the reference stores into a q-dtype tensor; round with ``.to(q.dtype)``)."""
+    B, H, N, D = q.shape
+    assert k.shape == q.shape and N % block_m == 0 and N % block_n == 0, "Simple for now (main_torch_only.py:196)"
+    dt = q.dtype
+    out = torch.empty((B, H, N, D), dtype=torch.float32)
+    qf, kf, vf = q.cpu(), k.cpu(), v.cpu()
+    for q_start in range(0, N, block_m):
+        q_tile = qf[:, :, q_start:q_start + block_m, :]
+        g_score = torch.zeros((B, H, block_m, D), dtype=torch.float32)
+        g_sum = torch.zeros((B, H, block_m, 1), dtype=torch.float32)
+        g_max = torch.full((B, H, block_m, 1), -math.inf, dtype=torch.float32)
+        for kv_start in range(0, N, block_n):
+            k_tile = kf[:, :, kv_start:kv_start + block_n, :]
+            v_tile = vf[:, :, kv_start:kv_start + block_n, :]
+            qk = torch.matmul(q_tile.float(), k_tile.float().transpose(2, 3))  # 16-bit products, fp32 accumulate
+            if is_causal:
+                rows = q_start + torch.arange(block_m)[:, None]
+                cols = kv_start + torch.arange(block_n)[None, :]
+                qk = qk.masked_fill(cols > rows, -math.inf)
+            qk = qk * softmax_scale
+            local_max = qk.max(dim=-1, keepdim=True).values
+            new_max = torch.maximum(local_max, g_max)
+            safe_max = torch.where(torch.isinf(new_max), torch.zeros_like(new_max), new_max)
+            rescale = torch.exp(g_max - safe_max)
+            local_score = torch.exp(qk - safe_max)
+            g_sum = g_sum * rescale + local_score.sum(dim=-1, keepdim=True)
+            g_score = g_score * rescale + torch.matmul(local_score.to(dt).float(), v_tile.float())
+            g_max = new_max
+        out[:, :, q_start:q_start + block_m, :] = g_score / g_sum
+    return out
+
+
+_ref_mod = None
+
+
+def ref_kernels():
+    """The reference's own compiled CPU module ``_kernels`` (naive_attn / flash_attn), or None
+    when oracle/_ref has not been built (it can only be built where /root/reference exists)."""
+    global _ref_mod
+    if _ref_mod is None:
+        cands = glob.glob(os.path.join(_HERE, "_ref", "_kernels*.so"))
+        if not cands:
+            return None
+        spec = importlib.util.spec_from_file_location("_kernels", cands[0])
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _ref_mod = mod
+    return _ref_mod
+
+
+def make_inputs(B, H, N, D, dtype=torch.float16, seed=0, std=0.5, Hk=None, Nk=None, dist="normal"):
+    """The reference's input recipe (flash_attention_cutlass/test.py:13-17: normal(0, 0.5) cast to
+    the dtype; flash_attention_c/test.py:35-40: uniform [0,1) fp32), generated on CPU from a seed
+    so the oracle and the GPU see identical bits."""
+    g = torch.Generator().manual_seed(seed)
+    Hk = H if Hk is None else Hk
+    Nk = N if Nk is None else Nk
+
+    def mk(shape):
+        if dist == "normal":
+            return torch.empty(shape, dtype=torch.float32).normal_(0.0, std, generator=g).to(dtype)
+        return torch.rand(shape, dtype=torch.float32, generator=g).to(dtype)
+
+    return mk((B, H, N, D)), mk((B, Hk, Nk, D)), mk((B, Hk, Nk, D))

@@ -1,0 +1,123 @@
+"""ctypes binding of include/tfa.h.  Fails loudly when the HIP library is missing — there is
+no CPU or PyTorch fallback on the product path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtfa_hip.so")
+
+TFA_F16, TFA_BF16, TFA_F32 = 0, 1, 2
+
+# every symbol include/tfa.h declares
+SYMBOLS = (
+    "tfa_version",
+    "tfa_strerror",
+    "tfa_fwd",
+    "tfa_fwd_bhnd",
+    "tfa_fwd_bhnd_f32out",
+    "tfa_fwd_plan",
+    "tfa_fwd_time",
+    "tfa_set_variant",
+    "tfa_get_variant",
+    "tfa_num_variants",
+    "tfa_variant_name",
+    "tfa_fwd_work",
+)
+
+
+class TfaFwdParams(C.Structure):
+    """struct tfa_fwd_params (include/tfa.h)."""
+
+    _fields_ = [
+        ("q", C.c_void_p),
+        ("k", C.c_void_p),
+        ("v", C.c_void_p),
+        ("out", C.c_void_p),
+        ("lse", C.c_void_p),
+        ("B", C.c_int32),
+        ("H", C.c_int32),
+        ("Hk", C.c_int32),
+        ("Nq", C.c_int32),
+        ("Nk", C.c_int32),
+        ("D", C.c_int32),
+        ("q_stride", C.c_int64 * 3),
+        ("k_stride", C.c_int64 * 3),
+        ("v_stride", C.c_int64 * 3),
+        ("o_stride", C.c_int64 * 3),
+        ("softmax_scale", C.c_float),
+        ("is_causal", C.c_int32),
+        ("dtype", C.c_int32),
+        ("out_dtype", C.c_int32),
+    ]
+
+
+class TfaError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"tfa status {status}: {text}")
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the C-ABI library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C tiny-flash-attention_amd/csrc`. There is no fallback path."
+        )
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER(TfaFwdParams)
+    L.tfa_version.restype = C.c_int
+    L.tfa_strerror.restype = C.c_char_p
+    L.tfa_strerror.argtypes = [C.c_int]
+    L.tfa_fwd.restype = C.c_int
+    L.tfa_fwd.argtypes = [P, C.c_void_p]
+    bhnd = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_int, C.c_void_p]
+    L.tfa_fwd_bhnd.restype = C.c_int
+    L.tfa_fwd_bhnd.argtypes = bhnd
+    L.tfa_fwd_bhnd_f32out.restype = C.c_int
+    L.tfa_fwd_bhnd_f32out.argtypes = bhnd
+    L.tfa_fwd_plan.restype = C.c_int
+    L.tfa_fwd_plan.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.tfa_fwd_time.restype = C.c_int
+    L.tfa_fwd_time.argtypes = [P, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+    L.tfa_set_variant.restype = C.c_int
+    L.tfa_set_variant.argtypes = [C.c_int]
+    L.tfa_get_variant.restype = C.c_int
+    L.tfa_num_variants.restype = C.c_int
+    L.tfa_variant_name.restype = C.c_char_p
+    L.tfa_variant_name.argtypes = [C.c_int]
+    L.tfa_fwd_work.restype = C.c_int
+    L.tfa_fwd_work.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != 0:
+        raise TfaError(status, lib().tfa_strerror(status).decode())
+
+
+def strerror(status):
+    return lib().tfa_strerror(status).decode()
+
+
+def set_variant(v):
+    check(lib().tfa_set_variant(int(v)))
+
+
+def get_variant():
+    return lib().tfa_get_variant()
+
+
+def num_variants():
+    return lib().tfa_num_variants()
+
+
+def variant_name(v):
+    return lib().tfa_variant_name(int(v)).decode()

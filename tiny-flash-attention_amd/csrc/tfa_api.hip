@@ -1,0 +1,233 @@
+// tfa_api.hip — the extern "C" boundary declared in include/tfa.h.
+// Validates a problem descriptor, fills the kernel arguments, picks a kernel variant and
+// launches on the caller's stream.  Mirrors what the reference host entry does
+// (flash_attention_cutlass/csrc/flash_attention.cu:320-361 set_params_fprop, :731-739 dispatch,
+//  :741-772 entry) minus allocation (the caller owns all buffers) and minus the device sync.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "tfa.h"
+#include "tfa_launch.h"
+
+namespace tfa {
+// defined in tfa_fwd_inst_<dtype>_<D>.hip
+template <> hipError_t launch_fwd<__bf16, 64>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
+template <> hipError_t launch_fwd<__bf16, 128>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
+template <> hipError_t launch_fwd<_Float16, 64>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
+template <> hipError_t launch_fwd<_Float16, 128>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
+}  // namespace tfa
+
+namespace {
+
+int g_variant = -1;   // -1 = automatic
+
+int pick_variant(const tfa_fwd_params* p) {
+  if (g_variant >= 0) return g_variant;
+  (void)p;
+  return tfa::kDefaultVariant;
+}
+
+// extent in bytes of one (b,h) slice: rows 0..N-1 at row stride, D contiguous elements each
+bool slice_bytes(int64_t n, int64_t row_stride, int d, int esize, unsigned* out) {
+  const int64_t bytes = ((n - 1) * row_stride + d) * esize;
+  // keep every byte offset the kernel forms (up to one block past the end) inside int32
+  const int64_t reach = ((n + 512) * row_stride + d) * esize;
+  if (bytes <= 0 || reach >= (int64_t)0x7fffffff) return false;
+  *out = (unsigned)bytes;
+  return true;
+}
+
+int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
+  if (!p) return TFA_ERR_NULL;
+  if (!p->q || !p->k || !p->v || !p->out) return TFA_ERR_NULL;
+  if (p->dtype != TFA_F16 && p->dtype != TFA_BF16) return TFA_ERR_DTYPE;
+  if (p->out_dtype != p->dtype && p->out_dtype != TFA_F32) return TFA_ERR_DTYPE;
+  if (p->D != 64 && p->D != 128) return TFA_ERR_HEAD_DIM;
+  if (p->B <= 0 || p->H <= 0 || p->Hk <= 0 || p->Nq <= 0 || p->Nk <= 0) return TFA_ERR_SHAPE;
+  if (p->H % p->Hk != 0) return TFA_ERR_SHAPE;
+  if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
+  if (variant < 0 || variant >= tfa::kNumVariants) return TFA_ERR_VARIANT;
+  const int esz = 2, osz = (p->out_dtype == TFA_F32) ? 4 : 2;
+  const int64_t* st[4] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride};
+  for (int t = 0; t < 4; ++t) {
+    const int es = (t == 3) ? osz : esz;
+    for (int i = 0; i < 3; ++i) {
+      if (st[t][i] < 0) return TFA_ERR_STRIDE;
+      if ((st[t][i] * es) % 16 != 0) return TFA_ERR_STRIDE;   // 16-byte vector access on every row
+    }
+    if (st[t][2] < p->D) return TFA_ERR_STRIDE;               // rows must not overlap
+  }
+  if (((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->out) & 15) return TFA_ERR_ALIGN;
+  if (p->lse && ((uintptr_t)p->lse & 3)) return TFA_ERR_ALIGN;
+
+  memset(a, 0, sizeof(*a));
+  a->q = p->q; a->k = p->k; a->v = p->v; a->o = p->out; a->lse = p->lse;
+  a->B = p->B; a->H = p->H; a->Hk = p->Hk; a->Nq = p->Nq; a->Nk = p->Nk;
+  a->qs_b = p->q_stride[0]; a->qs_h = p->q_stride[1]; a->qs_n = p->q_stride[2];
+  a->ks_b = p->k_stride[0]; a->ks_h = p->k_stride[1]; a->ks_n = p->k_stride[2];
+  a->vs_b = p->v_stride[0]; a->vs_h = p->v_stride[1]; a->vs_n = p->v_stride[2];
+  a->os_b = p->o_stride[0]; a->os_h = p->o_stride[1]; a->os_n = p->o_stride[2];
+  if (!slice_bytes(p->Nq, a->qs_n, p->D, esz, &a->q_bytes)) return TFA_ERR_STRIDE;
+  if (!slice_bytes(p->Nk, a->ks_n, p->D, esz, &a->k_bytes)) return TFA_ERR_STRIDE;
+  if (!slice_bytes(p->Nk, a->vs_n, p->D, esz, &a->v_bytes)) return TFA_ERR_STRIDE;
+  if (!slice_bytes(p->Nq, a->os_n, p->D, osz, &a->o_bytes)) return TFA_ERR_STRIDE;
+  a->scale = p->softmax_scale;
+  a->scale_log2 = p->softmax_scale * 1.4426950408889634f;
+  const int bm = tfa::block_m_of(variant);
+  a->nmb = (p->Nq + bm - 1) / bm;
+  const int64_t nbh = (int64_t)p->B * p->H;
+  if (nbh * a->nmb >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
+  a->nbh = (int)nbh;
+  return TFA_OK;
+}
+
+int run(const tfa_fwd_params* p, void* stream, tfa::LaunchGeom* geom, bool dry) {
+  const int variant = pick_variant(p);
+  tfa::KArgs a;
+  const int st = validate(p, &a, variant);
+  if (st != TFA_OK) return st;
+  const bool causal = p->is_causal != 0;
+  const bool f32out = p->out_dtype == TFA_F32;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (p->dtype == TFA_BF16) {
+    e = (p->D == 128) ? tfa::launch_fwd<__bf16, 128>(a, causal, f32out, variant, s, geom, dry)
+                      : tfa::launch_fwd<__bf16, 64>(a, causal, f32out, variant, s, geom, dry);
+  } else {
+    e = (p->D == 128) ? tfa::launch_fwd<_Float16, 128>(a, causal, f32out, variant, s, geom, dry)
+                      : tfa::launch_fwd<_Float16, 64>(a, causal, f32out, variant, s, geom, dry);
+  }
+  return (int)e;
+}
+
+void fill_bhnd(tfa_fwd_params* p, const void* q, const void* k, const void* v, void* out, float* lse,
+               int B, int H, int N, int D, float scale, int causal, int dtype, int out_dtype) {
+  memset(p, 0, sizeof(*p));
+  p->q = q; p->k = k; p->v = v; p->out = out; p->lse = lse;
+  p->B = B; p->H = H; p->Hk = H; p->Nq = N; p->Nk = N; p->D = D;
+  const int64_t sb = (int64_t)H * N * D, sh = (int64_t)N * D, sn = D;
+  int64_t* st[4] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride};
+  for (int t = 0; t < 4; ++t) { st[t][0] = sb; st[t][1] = sh; st[t][2] = sn; }
+  p->softmax_scale = scale; p->is_causal = causal; p->dtype = dtype; p->out_dtype = out_dtype;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tfa_version(void) { return TFA_VERSION; }
+
+const char* tfa_strerror(int status) {
+  switch (status) {
+    case TFA_OK: return "success";
+    case TFA_ERR_NULL: return "tfa: a required pointer is NULL";
+    case TFA_ERR_DTYPE: return "tfa: unsupported dtype (q/k/v must be fp16 or bf16; out must match or be fp32)";
+    case TFA_ERR_HEAD_DIM: return "tfa: unsupported head dim (supported: 64, 128)";
+    case TFA_ERR_SHAPE: return "tfa: bad shape (sizes must be positive and H % Hk == 0)";
+    case TFA_ERR_STRIDE: return "tfa: bad stride (must be >=0, rows 16-byte aligned and non-overlapping, slice < 2 GiB)";
+    case TFA_ERR_ALIGN: return "tfa: base pointers must be 16-byte aligned";
+    case TFA_ERR_VARIANT: return "tfa: unknown kernel variant";
+    case TFA_ERR_SCALE: return "tfa: softmax_scale must be finite and > 0";
+    default: break;
+  }
+  if (status > 0) return hipGetErrorString((hipError_t)status);
+  return "tfa: unknown status";
+}
+
+int tfa_fwd(const tfa_fwd_params* p, void* stream) { return run(p, stream, nullptr, false); }
+
+int tfa_fwd_bhnd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int N,
+                 int D, float softmax_scale, int is_causal, int dtype, void* stream) {
+  tfa_fwd_params p;
+  fill_bhnd(&p, q, k, v, out, lse, B, H, N, D, softmax_scale, is_causal, dtype, dtype);
+  return run(&p, stream, nullptr, false);
+}
+
+int tfa_fwd_bhnd_f32out(const void* q, const void* k, const void* v, float* out, float* lse, int B, int H,
+                        int N, int D, float softmax_scale, int is_causal, int dtype, void* stream) {
+  tfa_fwd_params p;
+  fill_bhnd(&p, q, k, v, out, lse, B, H, N, D, softmax_scale, is_causal, dtype, TFA_F32);
+  return run(&p, stream, nullptr, false);
+}
+
+int tfa_fwd_plan(const tfa_fwd_params* p, int* grid, int* block, int* lds_bytes) {
+  tfa::LaunchGeom g = {0, 0, 0};
+  const int st = run(p, nullptr, &g, true);
+  if (st != 0) return st;
+  if (grid) *grid = g.grid;
+  if (block) *block = g.block;
+  if (lds_bytes) *lds_bytes = g.lds;
+  return TFA_OK;
+}
+
+int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, float* avg_ms) {
+  if (!avg_ms || iters <= 0 || warmup < 0) return TFA_ERR_NULL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int i = 0; i < warmup; ++i) {
+    const int st = run(p, stream, nullptr, false);
+    if (st != 0) return st;
+  }
+  hipEvent_t e0, e1;
+  hipError_t e = hipEventCreate(&e0);
+  if (e != hipSuccess) return (int)e;
+  e = hipEventCreate(&e1);
+  if (e != hipSuccess) { (void)hipEventDestroy(e0); return (int)e; }
+  int st = 0;
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters && st == 0; ++i) st = run(p, stream, nullptr, false);
+  (void)hipEventRecord(e1, s);
+  e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (st != 0) return st;
+  if (e != hipSuccess) return (int)e;
+  *avg_ms = ms / (float)iters;
+  return TFA_OK;
+}
+
+int tfa_set_variant(int variant) {
+  if (variant < -1 || variant >= tfa::kNumVariants) return TFA_ERR_VARIANT;
+  g_variant = variant;
+  return TFA_OK;
+}
+int tfa_get_variant(void) { return g_variant; }
+int tfa_num_variants(void) { return tfa::kNumVariants; }
+const char* tfa_variant_name(int variant) {
+  if (variant < 0 || variant >= tfa::kNumVariants) return "auto";
+  return tfa::kVariants[variant].name;
+}
+
+int tfa_fwd_work(const tfa_fwd_params* p, double* flops, double* bytes) {
+  if (!p) return TFA_ERR_NULL;
+  const double bh = (double)p->B * p->H;
+  double pairs;   // visible (query,key) pairs per (b,h)
+  if (p->is_causal) {
+    // row i sees min(Nk, max(0, i + 1 + Nk - Nq)) keys
+    pairs = 0;
+    const long long shift = (long long)p->Nk - p->Nq;
+    if (shift >= 0) {
+      pairs = (double)p->Nq * (double)(shift) + 0.5 * (double)p->Nq * ((double)p->Nq + 1.0);
+    } else {
+      const double n = (double)p->Nk;   // only the last Nk rows see anything
+      pairs = 0.5 * n * (n + 1.0);
+    }
+    // the reference's convention is exactly half of the full square when Nq == Nk
+    if (p->Nq == p->Nk) pairs = 0.5 * (double)p->Nq * (double)p->Nk;
+  } else {
+    pairs = (double)p->Nq * (double)p->Nk;
+  }
+  if (flops) *flops = 4.0 * bh * pairs * p->D;
+  if (bytes) {
+    const double osz = (p->out_dtype == TFA_F32) ? 4.0 : 2.0;
+    const double bkv = (double)p->B * p->Hk;
+    *bytes = bh * p->Nq * p->D * 2.0 + 2.0 * bkv * p->Nk * p->D * 2.0 + bh * p->Nq * p->D * osz +
+             (p->lse ? bh * p->Nq * 4.0 : 0.0);
+  }
+  return TFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,392 @@
+// tfa_fwd_kernel.h — the fused FlashAttention-2 forward tile loop for gfx950 (MI355X, CDNA4).
+//
+// Hand-written for 64-wide wavefronts and the 32x32x16 bf16/f16 MFMA; not derived from the
+// reference's CuTe/SM80 kernel.  What it computes is the reference's hot loop
+// (flash_attention_cutlass/csrc/flash_attention.cu:373-685): per query block, stream K/V
+// blocks, S = QK^T, online softmax, O += PV, normalise, write O and LSE.
+//
+// Design (see DESIGN.md for the numbers):
+//   * workgroup = NW waves; wave w owns 32 query rows; KV block = 64 keys.
+//   * "swapped" first GEMM: S^T = K Q^T, so the 32x32 MFMA result puts ONE query row in each
+//     lane (column = lane&31) and keys in registers -> row max / row sum are in-lane
+//     reductions plus ONE half-wave exchange (v_permlane32_swap); running max/sum live in VGPRs.
+//   * second GEMM O^T += V^T P^T with P^T taken straight from the S^T accumulator registers
+//     (rounded to 16 bit): the MFMA k-index is permuted consistently for P and V, so no
+//     cross-lane movement of P is needed at all.
+//   * K tile in LDS row-major with a 16-byte-chunk XOR swizzle (conflict-free ds_read_b128);
+//     V tile in LDS as [8-key][32-col] sub-tiles read with ds_read_b64_tr_b16 (hardware
+//     transpose) — each half-wave reads one contiguous 256 B span.
+//   * K/V global->register->LDS staging is split (issue loads for tile j+1 before the compute
+//     of tile j, write them to the other LDS buffer after it): one barrier per KV tile.
+//   * buffer loads/stores with hardware bounds checking give ragged N for free
+//     (out-of-range rows read as 0 / are not written).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tfa {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// Kernel arguments (device view of tfa_fwd_params; strides in ELEMENTS).
+struct KArgs {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* lse;
+  int B, H, Hk, Nq, Nk;
+  int nmb;          // number of query blocks per (b,h)
+  int nbh;          // B*H
+  long long qs_b, qs_h, qs_n;
+  long long ks_b, ks_h, ks_n;
+  long long vs_b, vs_h, vs_n;
+  long long os_b, os_h, os_n;
+  unsigned q_bytes, k_bytes, v_bytes, o_bytes;   // extent of one (b,h) slice, for the buffer descriptors
+  float scale;      // softmax_scale
+  float scale_log2; // softmax_scale * log2(e)
+};
+
+template <typename T> struct Elem;
+template <> struct Elem<__bf16> {
+  using x8 = bf16x8;
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Elem<_Float16> {
+  using x8 = f16x8;
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+static __device__ __forceinline__ u32x4 lds_read_b128(const char* base, int off) {
+  return *reinterpret_cast<const u32x4*>(base + off);
+}
+static __device__ __forceinline__ void lds_write_b128(char* base, int off, u32x4 v) {
+  *reinterpret_cast<u32x4*>(base + off) = v;
+}
+// ds_read_b64_tr_b16: within each 16-lane group the 16 lanes x 4 halfwords that the lanes
+// address are transposed: lane i receives halfword (i&3) of the four lanes 4j+(i>>2), j=0..3.
+static __device__ __forceinline__ s16x4 lds_read_tr16_b64(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(p));
+}
+
+static __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// max over the two half-waves (lane l and lane l^32) — one v_permlane32_swap + one v_max.
+static __device__ __forceinline__ float pair_max(float x) {
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+static __device__ __forceinline__ float pair_sum(float x) {
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
+// ---- LDS layouts -------------------------------------------------------------------------
+// K tile [64 keys][D] row-major, 16-byte chunk index XOR-swizzled by the row so that the 16
+// lanes of a ds_read_b128 service group (16 different keys, same chunk) hit 16 different
+// 16-byte slots of the 256-byte bank row.
+template <int D> static __device__ __forceinline__ int k_swz(int row) {
+  return D == 128 ? (row & 15) : ((row >> 1) & 7);
+}
+template <int D> static __device__ __forceinline__ int k_lds_off(int row, int chunk) {
+  return row * (D * 2) + ((chunk ^ k_swz<D>(row)) << 4);
+}
+// V tile [64 keys][D]: sub-tiles of [8 key-rows][32 cols] (512 B).  Key k of a 16-key slot s
+// goes to sub-tile half (k>>2)&1 (the half-wave that consumes it) and row ((k>>3)&1)*4+(k&3).
+// With this order the MFMA k-index of the PV product is {0-3,8-11 | 4-7,12-15} per half-wave,
+// which is exactly how the S^T accumulator hands each lane its P values.
+template <int D> static __device__ __forceinline__ int v_lds_off(int key, int chunk /*16B chunk in row*/) {
+  const int s = key >> 4, kk = key & 15;
+  const int hi = (kk >> 2) & 1, half = kk >> 3, r4 = kk & 3;
+  return (((s * 2 + hi) * (D / 32) + (chunk >> 2)) << 9) + ((half * 4 + r4) << 6) + ((chunk & 3) << 4);
+}
+
+// Variant flags
+constexpr int VF_TRREAD = 1;     // V fragments by ds_read_b64_tr_b16 (else 16-bit gathers)
+constexpr int VF_NOSKIP = 2;     // always rescale O (no exact alpha==1 skip)
+
+template <typename T, int D, int NW, bool CAUSAL, bool F32OUT, int VF>
+__global__ __launch_bounds__(NW * 64, 2) void fwd_kernel(const KArgs p) {
+  using E = Elem<T>;
+  using X8 = typename E::x8;
+  constexpr int BM = NW * 32;       // query rows per workgroup
+  constexpr int BN = 64;            // keys per tile
+  constexpr int NT = NW * 64;       // threads
+  constexpr int CPR = D / 8;        // 16-byte chunks per row
+  constexpr int TILE_BYTES = BN * D * 2;
+  constexpr int NCH = BN * CPR / NT;  // staging chunks per thread per tensor
+  constexpr int DS = D / 16;        // k-slots of the QK^T contraction
+  constexpr int DT = D / 32;        // 32-wide d tiles of O
+  static_assert(NCH >= 1, "tile too small for the workgroup");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const kl = smem;                    // K buffers 0,1
+  char* const vl = smem + 2 * TILE_BYTES;   // V buffers 0,1
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 31;
+  const int hi = lane >> 5;
+
+  // ---- workgroup -> (b,h, query block): heads of one XCD stay together, heavy blocks first
+  int bh, mb;
+  {
+    const int id = blockIdx.x;
+    if ((p.nbh & 7) == 0) {
+      const int x = id & 7, s = id >> 3;
+      bh = x + 8 * (s / p.nmb);
+      mb = s % p.nmb;
+    } else {
+      bh = id / p.nmb;
+      mb = id % p.nmb;
+    }
+    if (CAUSAL) mb = p.nmb - 1 - mb;
+  }
+  const int b = bh / p.H;
+  const int h = bh - b * p.H;
+  const int hk = h / (p.H / p.Hk);
+  const int q0 = mb * BM;
+  const int shift = p.Nk - p.Nq;           // causal: key j visible to row i iff j <= i + shift
+
+  // number of KV tiles this workgroup walks
+  int kv_end = p.Nk;
+  if (CAUSAL) {
+    const int lim = q0 + BM + shift;       // one past the last key any row of the block sees
+    kv_end = lim < kv_end ? lim : kv_end;
+  }
+  const int nt = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+
+  const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
+  const T* kbase = reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h;
+  const T* vbase = reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h;
+  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, p.q_bytes, 0x00020000);
+  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
+  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
+
+  // ---- staging geometry (constant per thread) ----------------------------------------------
+  int st_koff[NCH], st_voff[NCH];            // byte offset inside the (b,h) slice for tile 0
+  int st_klds[NCH], st_vlds[NCH];            // LDS byte offsets inside one tile buffer
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * NT;
+    const int row = c / CPR, cc = c % CPR;
+    st_koff[i] = row * (int)p.ks_n * 2 + cc * 16;
+    st_voff[i] = row * (int)p.vs_n * 2 + cc * 16;
+    st_klds[i] = k_lds_off<D>(row, cc);
+    st_vlds[i] = v_lds_off<D>(row, cc);
+  }
+  const int k_tile_stride = BN * (int)p.ks_n * 2;
+  const int v_tile_stride = BN * (int)p.vs_n * 2;
+
+  u32x4 kst[NCH], vst[NCH];
+  auto stage_load = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      kst[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rs, st_koff[i] + j * k_tile_stride, 0, 0);
+      vst[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rs, st_voff[i] + j * v_tile_stride, 0, 0);
+    }
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      lds_write_b128(kl, buf * TILE_BYTES + st_klds[i], kst[i]);
+      lds_write_b128(vl, buf * TILE_BYTES + st_vlds[i], vst[i]);
+    }
+  };
+
+  // ---- prologue: first K/V tile in flight, then Q fragments --------------------------------
+  if (nt > 0) stage_load(0);
+
+  const int my_row = q0 + wave * 32 + qi;    // the query row this lane owns
+  X8 qf[DS];
+  {
+    const int qoff = my_row * (int)p.qs_n * 2 + hi * 16;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, qoff + s * 32, 0, 0);
+      qf[s] = __builtin_bit_cast(X8, t);
+    }
+  }
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -1e30f;   // running max of the raw (unscaled) scores
+  float l_run = 0.f;      // this lane's partial row sum (its 32 keys per tile)
+
+  if (nt > 0) stage_write(0);
+  __syncthreads();
+
+  // per-lane LDS read bases
+  const int k_rd_base = qi * (D * 2);                       // key row (lane&31) of key-tile 0
+  const int k_rd_swz = k_swz<D>(qi);
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
+  const int v_ga_base = (hi * DT << 9) + (qi << 1);         // gather variant: column (lane&31)
+
+  // last tile this wave needs (causal): rows [q0+32w, q0+32w+32)
+  const int wave_row0 = q0 + wave * 32;
+  const int wave_last_tile = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (nt - 1);
+
+  const float sc = p.scale_log2;
+
+  auto tile_body = [&](int j, int buf) {
+    const bool has_next = (j + 1 < nt);
+    if (has_next) stage_load(j + 1);
+
+    if (j <= wave_last_tile) {
+      const char* kb = kl + buf * TILE_BYTES;
+      const char* vb = vl + buf * TILE_BYTES;
+
+      // ---- S^T = K Q^T : two 32-key tiles x DS k-slots -------------------------------------
+      f32x16 sacc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < DS; ++s) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int off = k_rd_base + t * 32 * (D * 2) + (((2 * s + hi) ^ k_rd_swz) << 4);
+          X8 kf = __builtin_bit_cast(X8, lds_read_b128(kb, off));
+          sacc[t] = E::mfma(kf, qf[s], sacc[t]);
+        }
+      }
+
+      // ---- masking (causal diagonal / ragged last tile) -----------------------------------
+      const int key0 = j * BN;
+      bool need_mask = (key0 + BN > p.Nk);
+      if (CAUSAL) need_mask = need_mask || (key0 + BN - 1 > wave_row0 + shift);
+      if (need_mask) {
+        int lim = p.Nk - 1;                              // last valid key
+        if (CAUSAL) { const int c = my_row + shift; lim = c < lim ? c : lim; }
+        lim -= key0 + 4 * hi;                            // compare against the in-tile key offset
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ko = 32 * t + (r & 3) + 8 * (r >> 2);
+            if (ko > lim) sacc[t][r] = -INFINITY;
+          }
+      }
+
+      // ---- online softmax (row = lane&31; the two half-waves hold different keys) ---------
+      float mloc = sacc[0][0];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[t][r]);
+      mloc = pair_max(mloc);
+      const float m_new = fmaxf(m_run, mloc);
+      const bool changed = (m_new != m_run);
+      if ((VF & VF_NOSKIP) || __any(changed)) {
+        const float alpha = fast_exp2((m_run - m_new) * sc);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      }
+      m_run = m_new;
+      const float msc = m_new * sc;
+      X8 pk[4];
+      float lsum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = fast_exp2(fmaf(sacc[t][r], sc, -msc));
+          lsum += e;
+          pk[t * 2 + (r >> 3)][r & 7] = (T)e;
+        }
+      l_run += lsum;
+
+      // ---- O^T += V^T P^T -------------------------------------------------------------------
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          s16x8 vf;
+          if (VF & VF_TRREAD) {
+            const char* a = vb + v_rd_base + (s * 2 * DT << 9) + (d << 9);
+            s16x4 lo = lds_read_tr16_b64(a);
+            s16x4 hh = lds_read_tr16_b64(a + 256);
+            vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+          } else {
+            const char* a = vb + v_ga_base + (s * 2 * DT << 9) + (d << 9);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vf[e] = *reinterpret_cast<const short*>(a + (e << 6));
+          }
+          oacc[d] = E::mfma(__builtin_bit_cast(X8, vf), pk[s], oacc[d]);
+        }
+      }
+    }
+
+    if (has_next) stage_write(buf ^ 1);
+    __syncthreads();
+  };
+
+  for (int j = 0; j < nt; j += 2) {
+    tile_body(j, 0);
+    if (j + 1 < nt) tile_body(j + 1, 1);
+  }
+
+  // ---- epilogue: normalise, LSE, store ------------------------------------------------------
+  const float l_tot = pair_sum(l_run);
+  const bool empty = !(l_tot > 0.f);                       // l == 0 or NaN  (flash_attention.cu:620)
+  const float inv = empty ? 1.f : 1.f / l_tot;
+
+  if (p.lse != nullptr && hi == 0 && my_row < p.Nq) {
+    // LSE = m*scale + ln(l)  (flash_attention.cu:623); ln via log2
+    const float lse = empty ? INFINITY : (m_run * p.scale + __builtin_amdgcn_logf(l_tot) * 0.6931471805599453f);
+    p.lse[(long long)bh * p.Nq + my_row] = lse;
+  }
+
+  // lane holds, for its row, d = 32*dt + 8*g + 4*hi + {0..3}  (g = r>>2)
+  if (F32OUT) {
+    float* obase = reinterpret_cast<float*>(p.o) + b * p.os_b + h * p.os_h;
+    auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+    const int ooff = my_row * (int)p.os_n * 4 + hi * 16;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v4 = {oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, ooff + (d * 32 + g * 8) * 4, 0, 0);
+      }
+  } else {
+    T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
+    auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+    const int ooff = my_row * (int)p.os_n * 2 + hi * 8;
+    typedef __attribute__((ext_vector_type(4))) T t4;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        t4 v4 = {(T)(oacc[d][4 * g + 0] * inv), (T)(oacc[d][4 * g + 1] * inv), (T)(oacc[d][4 * g + 2] * inv), (T)(oacc[d][4 * g + 3] * inv)};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, ooff + (d * 32 + g * 8) * 2, 0, 0);
+      }
+  }
+}
+
+}  // namespace tfa

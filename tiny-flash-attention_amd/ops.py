@@ -1,0 +1,159 @@
+"""Reference-named operators over the C ABI (include/tfa.h).
+
+Argument meaning, order, return shapes and error behaviour follow the reference's pybind
+functions; the compute is the hand-written HIP kernel in csrc/.  Nothing here falls back to
+PyTorch or the CPU: if the library is missing or the device is not a GPU the call raises.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float16: _lib.TFA_F16, torch.bfloat16: _lib.TFA_BF16}
+
+
+def _check_input(x, name):
+    # CHECK_INPUT of the reference (flash_attention_cutlass/include/attention_api.cuh:12-18)
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _strides_bhnd(t, layout):
+    """(batch, head, row) element strides of a 4-D tensor given its logical layout."""
+    if layout == "bhnd":
+        return t.stride(0), t.stride(1), t.stride(2)
+    if layout == "bnhd":
+        return t.stride(0), t.stride(2), t.stride(1)
+    raise ValueError(f"unknown layout {layout!r}")
+
+
+def flash_attn_fwd(q, k, v, is_causal=False, softmax_scale=None, *, layout="bhnd", out_f32=False,
+                   return_lse=True, out=None):
+    """General forward: q (B,H,Nq,D) / k,v (B,Hk,Nk,D) for ``layout='bhnd'`` or
+    (B,N,H,D) for ``layout='bnhd'``; any batch/head/row strides, unit stride along D.
+    Returns ``(out, lse)``; ``out`` has q's shape (fp32 when ``out_f32``), ``lse`` is (B,H,Nq) fp32.
+    Maps onto tfa_fwd (include/tfa.h); semantics per flash_attention_c/csrc/attn.cpp:101-169 and
+    flash_attention_cutlass/csrc/flash_attention.cu:536-630."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda:
+            raise RuntimeError(f"{n} must be a CUDA tensor")
+        if t.dim() != 4:
+            raise RuntimeError(f"{n} must be 4-D")
+        if t.stride(3) != 1:
+            raise RuntimeError(f"{n} must have unit stride along the head dimension")
+    if q.dtype not in _DT or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise TypeError(f"q,k,v must share dtype float16 or bfloat16 (got {q.dtype}, {k.dtype}, {v.dtype})")
+    if k.device != q.device or v.device != q.device:
+        raise RuntimeError("q,k,v must be on the same device")
+    if layout == "bhnd":
+        B, H, Nq, D = q.shape
+        Bk, Hk, Nk, Dk = k.shape
+    else:
+        B, Nq, H, D = q.shape
+        Bk, Nk, Hk, Dk = k.shape
+    if k.shape != v.shape or Bk != B or Dk != D:
+        raise RuntimeError(f"shape mismatch: q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)}")
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(D)
+
+    if out is None:
+        out = torch.empty(q.shape, dtype=torch.float32 if out_f32 else q.dtype, device=q.device)
+    lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device) if return_lse else None
+
+    p = _lib.TfaFwdParams()
+    p.q, p.k, p.v, p.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    p.lse = lse.data_ptr() if lse is not None else None
+    p.B, p.H, p.Hk, p.Nq, p.Nk, p.D = B, H, Hk, Nq, Nk, D
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", out)):
+        s = _strides_bhnd(t, layout)
+        arr = getattr(p, name)
+        arr[0], arr[1], arr[2] = s
+    p.softmax_scale = float(softmax_scale)
+    p.is_causal = 1 if is_causal else 0
+    p.dtype = _DT[q.dtype]
+    p.out_dtype = _lib.TFA_F32 if out.dtype == torch.float32 else _DT[out.dtype]
+    with torch.cuda.device(q.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().tfa_fwd(C.byref(p), C.c_void_p(stream)))
+    return out, lse
+
+
+def make_params(q, k, v, out, lse, is_causal, softmax_scale, layout="bhnd"):
+    """Build a TfaFwdParams for existing buffers (used by bench.py / tfa_fwd_time)."""
+    p = _lib.TfaFwdParams()
+    p.q, p.k, p.v, p.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    p.lse = lse.data_ptr() if lse is not None else None
+    if layout == "bhnd":
+        B, H, Nq, D = q.shape
+        _, Hk, Nk, _ = k.shape
+    else:
+        B, Nq, H, D = q.shape
+        _, Nk, Hk, _ = k.shape
+    p.B, p.H, p.Hk, p.Nq, p.Nk, p.D = B, H, Hk, Nq, Nk, D
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", out)):
+        s = _strides_bhnd(t, layout)
+        arr = getattr(p, name)
+        arr[0], arr[1], arr[2] = s
+    p.softmax_scale = float(softmax_scale)
+    p.is_causal = 1 if is_causal else 0
+    p.dtype = _DT[q.dtype]
+    p.out_dtype = _lib.TFA_F32 if out.dtype == torch.float32 else _DT[out.dtype]
+    return p
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's three operator entry points
+# ---------------------------------------------------------------------------------------------
+def flash_attention_v2_cutlass(q, k, v, is_causal, softmax_scale):
+    """``attention_cutlass.flash_attention_v2_cutlass(q, k, v, is_causal, softmax_scale) -> [out, lse]``
+    (flash_attention_cutlass/csrc/flash_attention.cu:741-772).  q,k,v: contiguous CUDA
+    (B,H,N,D) fp16/bf16; out like q; lse (B,H,N) fp32.  All five arguments are positional, as
+    in the reference binding (no py::arg, attention_api.cpp:6-10).  Launches on the current
+    stream and does not synchronise (the reference blocks; its callers synchronise anyway)."""
+    _check_input(q, "q")
+    _check_input(k, "k")
+    _check_input(v, "v")
+    out, lse = flash_attn_fwd(q, k, v, bool(is_causal), float(softmax_scale))
+    return [out, lse]
+
+
+def flash_attention_v2_cuda(q, k, v):
+    """``attention_cuda.flash_attention_v2_cuda(q, k, v) -> out``: non-causal, scale fixed to
+    1/sqrt(D) inside (flash_attention_cuda/csrc/flash_attention.cu:375-424, :389)."""
+    _check_input(q, "q")
+    _check_input(k, "k")
+    _check_input(v, "v")
+    out, _ = flash_attn_fwd(q, k, v, False, 1.0 / math.sqrt(q.shape[-1]), return_lse=False)
+    return out
+
+
+# the reference exports three names from attention_cuda; all compute the same function
+# (flash_attention_cuda/csrc/attention_api.cpp:6-14) — here they share the one kernel.
+flash_attention_v1_cuda = flash_attention_v2_cuda
+self_attention_cuda = flash_attention_v2_cuda
+
+
+def flash_attn(q, k, v, is_causal, softmax_scale):
+    """``_kernels.flash_attn(q, k, v, is_causal, softmax_scale) -> out``
+    (flash_attention_c/csrc/attn.cpp:237-262).  Same math as the CPU sibling, including its
+    bottom-right-aligned causal mask for Nq != Nk (attn.cpp:121-124) and strided inputs
+    (attn.cpp:171-203); tensors live on the GPU and are 16-bit here."""
+    out, _ = flash_attn_fwd(q, k, v, bool(is_causal), float(softmax_scale), return_lse=False)
+    return out
+
+
+# naive_attn computes the same function by a different route in the reference
+# (attn.cpp:35-98); the GPU path has one kernel.
+naive_attn = flash_attn
+
+
+def flash_attn_func(q, k, v, causal=False, softmax_scale=None):
+    """(B,N,H,D)-layout entry with the signature the reference's scripts use for comparison
+    (flash_attention_cutlass/test.py:71-76, flash_attention_py/main_torch_only.py:304);
+    supports GQA/MQA (fewer K/V heads)."""
+    out, _ = flash_attn_fwd(q, k, v, causal, softmax_scale, layout="bnhd", return_lse=False)
+    return out
