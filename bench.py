@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — the driver's benchmark contract for the FlashAttention-2 forward hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward pass of the hot path (tfa_fwd, include/tfa.h) over one synthetic batch
+already resident in HBM.  At N=1 the workload is BASELINE.json's headline configuration
+(B=4, H=32, N=4096, D=128, bf16, causal).  For N>1 every rank runs the same per-GPU batch on
+its own GPU (batch sharding, no data-path collective: each (b,h) pair is an independent
+problem, flash_attention_cutlass/csrc/flash_attention.cu:382,409,698) -> weak scaling.
+`--gather` adds the RCCL all-gather of the output shards (north_star's "trivial gather").
+
+Rank 0 prints ONE JSON line.  `value` = algorithmic flops of all ranks / wall time of the K
+steps (max over ranks).  `roofline.achieved` = algorithmic flops per launch / average launch
+duration measured with HIP events on the launch stream over the same timed region.
+`cpu_baseline` = the reference's own CPU path (oracle/_ref, kind "reference") or the C port
+(oracle/, kind "port") timed on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS_BF16 = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+CONFIGS = {
+    # name: (B, H, N, D, dtype, causal)  — BASELINE.json configs 2..5 (per-GPU shapes)
+    "cfg2": (4, 8, 1024, 64, torch.float16, False),
+    "cfg3": (4, 32, 4096, 128, torch.bfloat16, True),     # headline
+    "cfg4": (1, 16, 16384, 128, torch.bfloat16, False),
+    "cfg4c": (1, 16, 16384, 128, torch.bfloat16, True),
+    "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),     # per-GPU shard of B=64 over 8 GPUs
+}
+
+
+def cpu_baseline(B, H, N, D, causal, target_s=15.0):
+    """Time the reference CPU path on a bounded sample (heads of the same workload)."""
+    from oracle import oracle as O   # checker/baseline only — never on the product path
+
+    ref = O.ref_kernels()
+    kind = "reference" if ref is not None else "port"
+    fn = (lambda q, k, v, c, s: ref.flash_attn(q, k, v, c, s)) if ref is not None else O.flash_attn
+    cores = torch.get_num_threads() if ref is not None else O.num_threads()
+    sc = 1.0 / math.sqrt(D)
+
+    def run(heads):
+        q, k, v = O.make_inputs(1, heads, N, D, torch.float32, seed=0)
+        t0 = time.perf_counter()
+        fn(q, k, v, causal, sc)
+        return time.perf_counter() - t0
+
+    run(1)                                   # warm-up (OpenMP pool)
+    probe_heads = max(1, min(2, B * H))
+    t_probe = run(probe_heads)
+    per_head = t_probe / probe_heads
+    heads = int(max(probe_heads, min(B * H, target_s / max(per_head, 1e-6))))
+    t = run(heads) if heads > probe_heads else t_probe
+    flops = 4.0 * heads * N * N * D * (0.5 if causal else 1.0)
+    return {
+        "value": flops / t / 1e12,
+        "unit": "TFLOP/s",
+        "cores": int(os.cpu_count() if ref is not None else cores),
+        "threads": int(cores),
+        "kind": kind,
+        "sample": f"{heads} of {B * H} (b,h) heads of the same workload (N={N}, D={D}, causal={causal}), fp32, "
+                  f"{t:.2f} s; flash_attention_c flash_attn (attn.cpp:101-169)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--variant", type=int, default=-1, help="kernel variant (-1 = library default)")
+    ap.add_argument("--gather", action="store_true", help="also all-gather the output shards over RCCL")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+
+    import tiny_flash_attention_amd as tfa   # noqa: F401  (fails loudly if the HIP library is missing)
+    from tiny_flash_attention_amd import _lib, ops
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    B, H, N, D, dtype, causal = CONFIGS[args.config]
+    sc = 1.0 / math.sqrt(D)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(dtype)
+    q, k, v = mk(), mk(), mk()                     # reference input recipe (test.py:13-17), resident in HBM
+    out = torch.empty_like(q)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * B, H, N, D), dtype=dtype, device=dev) if (args.gather and world > 1) else None
+
+    _lib.set_variant(args.variant)
+    p = ops.make_params(q, k, v, out, lse, causal, sc)
+    L = _lib.lib()
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    pref = C.byref(p)
+
+    def step():
+        _lib.check(L.tfa_fwd(pref, sptr))
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1) / args.steps
+
+    if dist is not None:
+        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+
+    fl, by = C.c_double(), C.c_double()
+    L.tfa_fwd_work(pref, C.byref(fl), C.byref(by))
+    flops_step_rank = fl.value
+    total_flops = flops_step_rank * world * args.steps
+    value = total_flops / wall / 1e12
+    achieved = flops_step_rank / (ev_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        grid, block, ldsb = C.c_int(), C.c_int(), C.c_int()
+        L.tfa_fwd_plan(pref, C.byref(grid), C.byref(block), C.byref(ldsb))
+        line = {
+            "metric": "fwd TFLOPS + achieved %MFMA-roofline, (B=4,H=32,N=4096,D=128) bf16",
+            "value": value,
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16" if dtype == torch.bfloat16 else "f16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: FlashAttention-2 forward, per-GPU B={B} H={H} N={N} D={D} "
+                            f"{'causal' if causal else 'full'}, q/k/v normal(0,0.5) resident in HBM, scale=1/sqrt(D)",
+                "global_batch": B * world,
+                "per_gpu_batch": B,
+                "parallelism": f"batch-sharded x{world}" + (" + all_gather(out)" if gathered is not None else ""),
+                "kernel_variant": _lib.variant_name(args.variant) if args.variant >= 0 else "auto",
+                "launch": {"grid": grid.value, "block": block.value, "lds_bytes": ldsb.value},
+                "flops_per_step_per_gpu": flops_step_rank,
+                "algorithmic_bytes_per_step_per_gpu": by.value,
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_TFLOPS_BF16,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_TFLOPS_BF16,
+                "traffic": None,
+                "launch_ms": ev_ms,
+                "algorithmic_hbm_GBs": by.value / (ev_ms * 1e-3) / 1e9,
+                "hbm_frac": by.value / (ev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(B, H, N, D, causal)
+            except Exception as e:  # the baseline is a report, not the product: never fail the bench on it
+                line["cpu_baseline"] = {"value": None, "unit": "TFLOP/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": f"unavailable: {e!r}"}
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,289 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on identical seeded inputs, against the reference-generated golden
+fixtures, and — at BASELINE.json's full sizes — through size-independent properties.
+
+Tolerances (floating point; stated here once):
+  * 16-bit outputs vs the fp64 oracle: |d| <= 1e-2 absolute — the reference's own bar
+    (flash_attention_cutlass/test.py:87, flash_attention_c/test.py:82-83) — AND
+    |d| <= 1 ulp(out dtype) + 1e-3*max|ref|  (tighter: the result is the correctly rounded value
+    up to the fp32-path error below).
+  * fp32-output debug path vs the fp64 oracle that rounds P exactly like the kernel's contract
+    (oracle.exact64(p_round=dtype)): BASELINE.json's rtol=1e-3, as
+    |d| <= 1e-3*|ref| + 1e-3*max|ref|  (the additive term covers cancellation in sum_j P_ij v_j,
+    where a relative bound is meaningless; it is 1e-3 of the output scale).
+  * LSE (fp32) vs oracle: |d| <= 1e-3 (reference has no LSE test; values are O(ln N)).
+"""
+import math
+
+import pytest
+import torch
+
+from helpers import load_golden, ulp16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def tfa():
+    import tiny_flash_attention_amd as m
+    from tiny_flash_attention_amd import _lib
+
+    _lib.lib()  # must load: no fallback
+    yield m
+    _lib.set_variant(-1)
+
+
+def check(out16, out32, lse, ref, lse_ref, dtype):
+    scale = ref.abs().max().item()
+    d16 = (out16.float().cpu() - ref).abs()
+    assert d16.max().item() <= 1e-2, f"16-bit out: max|d|={d16.max().item():.3e} > reference bar 1e-2"
+    bound16 = ulp16(ref, dtype) + 1e-3 * scale
+    assert bool((d16 <= bound16).all()), f"16-bit out exceeds 1 ulp + 1e-3*scale: worst {(d16 - bound16).max().item():.3e}"
+    if out32 is not None:
+        d32 = (out32.cpu() - ref).abs()
+        bound32 = 1e-3 * ref.abs() + 1e-3 * scale
+        assert bool((d32 <= bound32).all()), f"fp32 out: rtol=1e-3 violated, worst excess {(d32 - bound32).max().item():.3e}"
+    if lse is not None:
+        fin = torch.isfinite(lse_ref)
+        assert bool((torch.isinf(lse.cpu()) == ~fin).all()), "LSE +inf pattern (empty rows) differs"
+        if fin.any():
+            dl = (lse.cpu()[fin] - lse_ref[fin]).abs().max().item()
+            assert dl <= 1e-3, f"LSE max|d|={dl:.3e}"
+
+
+def run_case(tfa, oracle, dev, dtype, B, H, N, D, causal, Hk=None, Nk=None, seed=0, scale=None, dist="normal"):
+    from tiny_flash_attention_amd import ops
+
+    q, k, v = oracle.make_inputs(B, H, N, D, dtype, seed=seed, Hk=Hk, Nk=Nk, dist=dist)
+    sc = 1.0 / math.sqrt(D) if scale is None else scale
+    ref, lse_ref = oracle.exact64(q, k, v, causal, sc, p_round=dtype, return_lse=True)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    out16, lse = ops.flash_attn_fwd(qd, kd, vd, causal, sc)
+    out32, _ = ops.flash_attn_fwd(qd, kd, vd, causal, sc, out_f32=True)
+    torch.cuda.synchronize()
+    check(out16, out32, lse, ref, lse_ref, dtype)
+
+
+SHAPES = [
+    # dtype, B, H, N, D, causal
+    (torch.bfloat16, 1, 2, 256, 128, False),
+    (torch.bfloat16, 1, 2, 256, 128, True),
+    (torch.bfloat16, 2, 3, 512, 128, True),
+    (torch.float16, 1, 2, 512, 64, False),
+    (torch.float16, 2, 2, 320, 64, True),       # N not a multiple of the query block
+    (torch.bfloat16, 1, 2, 200, 128, True),     # ragged: N not a multiple of 64
+    (torch.bfloat16, 1, 1, 77, 64, False),
+    (torch.float16, 1, 2, 1024, 128, True),
+    (torch.bfloat16, 1, 8, 1, 128, True),       # single row
+    (torch.float16, 1, 1, 63, 64, True),
+    (torch.bfloat16, 3, 1, 65, 64, False),
+]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype,B,H,N,D,causal", SHAPES)
+def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
+    from tiny_flash_attention_amd import _lib
+
+    if variant >= _lib.num_variants():
+        pytest.skip("variant not built")
+    _lib.set_variant(variant)
+    try:
+        run_case(tfa, oracle, dev, dtype, B, H, N, D, causal)
+    finally:
+        _lib.set_variant(-1)
+
+
+@pytest.mark.parametrize("Nq,Nk,causal", [(128, 384, True), (384, 128, True), (100, 333, False), (1, 1000, True), (257, 64, False)])
+def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal):
+    # K/V heads < Q heads and Nq != Nk with the reference's bottom-right causal offset
+    # (flash_attention_c/csrc/attn.cpp:121-124); (384,128,causal) has 256 EMPTY rows -> O=0, LSE=+inf
+    run_case(tfa, oracle, dev, torch.bfloat16, 1, 4, Nq, 128, causal, Hk=2, Nk=Nk, seed=7)
+    run_case(tfa, oracle, dev, torch.float16, 2, 6, Nq, 64, causal, Hk=1, Nk=Nk, seed=8)
+
+
+def test_baseline_cfg2_full(tfa, oracle, dev):
+    # BASELINE config 2: B=4 H=8 N=1024 D=64 fp16 non-causal (whole tensor vs oracle)
+    run_case(tfa, oracle, dev, torch.float16, 4, 8, 1024, 64, False, seed=2)
+
+
+def test_reference_quirk_scale_one_over_sqrt_seqlen(tfa, oracle, dev):
+    # flash_attention_cutlass/test.py:51-63 recipe: fp16 normal(0,0.5), B2 H8 N2048 D64 causal, scale 1/sqrt(SEQLEN)
+    run_case(tfa, oracle, dev, torch.float16, 2, 2, 2048, 64, True, seed=11, scale=1.0 / math.sqrt(2048))
+
+
+def test_uniform_inputs_c_recipe(tfa, oracle, dev):
+    # flash_attention_c/test.py:35-42 recipe: uniform [0,1) inputs, causal, scale 1/sqrt(D) (all-positive scores)
+    run_case(tfa, oracle, dev, torch.bfloat16, 3, 4, 128, 128, True, seed=0, dist="uniform")
+
+
+# ---------------------------------------------------------------------------------------------
+# golden vectors produced by the reference's own implementations (tests/golden/make_golden.py)
+# ---------------------------------------------------------------------------------------------
+def test_golden_tiny_py_cfg1(tfa, dev):
+    # BASELINE config 1 through the GPU kernel: scale=1, non-causal, inputs are fp16-representable
+    z, dt, q, k, v = load_golden("tiny_py_cfg1.npz")
+    want = torch.from_numpy(z["out_multihead"])
+    out, _ = tfa.flash_attention_v2_cutlass(q.to(dev), k.to(dev), v.to(dev), False, 1.0)
+    assert torch.allclose(out.float().cpu(), want, rtol=0, atol=1e-2)   # reference bar (main.py:95-99)
+    assert (out.float().cpu() - want).abs().max().item() <= 2e-3
+
+
+@pytest.mark.parametrize("causal", [0, 1])
+def test_golden_c_kernels(tfa, dev, causal):
+    z, dt, q, k, v = load_golden("c_kernels_seed0.npz")
+    sc = float(z["scale"])
+    want = torch.from_numpy(z[f"flash_c{causal}"])
+    got = tfa.flash_attn(q.to(dev), k.to(dev), v.to(dev), bool(causal), sc).float().cpu()
+    assert torch.allclose(got, want, rtol=0, atol=1e-2)                # flash_attention_c/test.py:82
+    assert (got - want).abs().max().item() <= 3e-3
+    if causal:
+        q2 = q[:, :, :48].contiguous()
+        got2 = tfa.flash_attn(q2.to(dev), k.to(dev), v.to(dev), True, sc).float().cpu()
+        assert (got2 - torch.from_numpy(z["flash_nq48_c1"])).abs().max().item() <= 3e-3
+
+
+@pytest.mark.parametrize("causal", [0, 1])
+def test_golden_torch_only_bnhd(tfa, dev, causal):
+    # (B,N,H,D) bf16 tensors through the strided entry; reference tolerance atol=rtol=1e-2 (main_torch_only.py:309-312)
+    z, dt, q, k, v = load_golden("torch_only_seed13.npz")
+    sc = float(z["scale"])
+    got = tfa.flash_attn_func(q.to(dev), k.to(dev), v.to(dev), causal=bool(causal), softmax_scale=sc).float().cpu()
+    for key in (f"safe_c{causal}", f"v2_c{causal}"):
+        torch.testing.assert_close(got, torch.from_numpy(z[key]), atol=1e-2, rtol=1e-2)
+
+
+# ---------------------------------------------------------------------------------------------
+# operator interface
+# ---------------------------------------------------------------------------------------------
+def test_reference_operator_signatures(tfa, oracle, dev):
+    q, k, v = oracle.make_inputs(2, 4, 256, 64, torch.float16, seed=4)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    res = tfa.flash_attention_v2_cutlass(qd, kd, vd, True, 0.125)
+    assert isinstance(res, list) and len(res) == 2
+    out, lse = res
+    assert out.shape == q.shape and out.dtype == q.dtype and lse.shape == (2, 4, 256) and lse.dtype == torch.float32
+    o2 = tfa.flash_attention_v2_cuda(qd, kd, vd)           # scale 1/sqrt(D), non causal
+    ref = oracle.exact64(q, k, v, False, 0.125, p_round=torch.float16)
+    assert (o2.float().cpu() - ref).abs().max().item() <= 2e-3
+    o3 = tfa.flash_attn(qd, kd, vd, True, 0.125)
+    assert torch.equal(o3, out)                            # same kernel, same bits
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        tfa.flash_attention_v2_cutlass(qd.transpose(1, 2), kd, vd, True, 0.125)
+    with pytest.raises(TypeError):
+        tfa.flash_attention_v2_cutlass(qd.float(), kd.float(), vd.float(), True, 0.125)
+
+
+def test_inputs_not_modified_and_deterministic(tfa, oracle, dev):
+    q, k, v = oracle.make_inputs(1, 2, 512, 128, torch.bfloat16, seed=9)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    a, la = tfa.flash_attention_v2_cutlass(qd, kd, vd, True, 0.1)
+    b, lb = tfa.flash_attention_v2_cutlass(qd, kd, vd, True, 0.1)
+    assert torch.equal(a, b) and torch.equal(la, lb)
+    assert torch.equal(qd.cpu(), q) and torch.equal(kd.cpu(), k) and torch.equal(vd.cpu(), v)
+
+
+# ---------------------------------------------------------------------------------------------
+# data-dependent branch: the exact "max unchanged -> skip the O rescale" path and late max jumps
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_late_max_jump_spike(tfa, oracle, dev, variant):
+    from tiny_flash_attention_amd import _lib, ops
+
+    q, k, v = oracle.make_inputs(1, 2, 1024, 128, torch.bfloat16, seed=21)
+    # spike a few K rows against a few Q rows so the running max jumps by a lot at chosen tiles
+    for (row, key, gain) in ((5, 700, 6.0), (300, 900, 9.0), (1000, 64, 4.0), (37, 1023, 12.0)):
+        k[0, :, key] = (q[0, :, row].float() * gain).to(torch.bfloat16)
+    sc = 1.0 / math.sqrt(128)
+    _lib.set_variant(variant)
+    try:
+        for causal in (False, True):
+            ref, lse_ref = oracle.exact64(q, k, v, causal, sc, p_round=torch.bfloat16, return_lse=True)
+            out16, lse = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc)
+            out32, _ = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc, out_f32=True)
+            check(out16, out32, lse, ref, lse_ref, torch.bfloat16)
+    finally:
+        _lib.set_variant(-1)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full sizes through size-independent properties
+# ---------------------------------------------------------------------------------------------
+def _headline(dev, B=4, H=32, N=4096, D=128, dtype=torch.bfloat16, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(dtype)
+    return mk(), mk(), mk()
+
+
+def test_headline_cfg3_sampled_heads_vs_oracle(tfa, oracle, dev):
+    # config 3 at full size; the oracle checks two whole (b,h) slices (fp64, a few seconds each)
+    q, k, v = _headline(dev)
+    sc = 1.0 / math.sqrt(128)
+    out, lse = tfa.flash_attention_v2_cutlass(q, k, v, True, sc)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all())
+    for (b, h) in ((0, 0), (3, 31)):
+        sl = lambda t: t[b:b + 1, h:h + 1].cpu()
+        ref, lse_ref = oracle.exact64(sl(q), sl(k), sl(v), True, sc, p_round=torch.bfloat16, return_lse=True)
+        check(sl(out), None, sl(lse), ref, lse_ref, torch.bfloat16)
+
+
+def test_headline_properties(tfa, dev):
+    q, k, v = _headline(dev, B=2)
+    sc = 1.0 / math.sqrt(128)
+    out, lse = tfa.flash_attention_v2_cutlass(q, k, v, True, sc)
+    # (1) every (b,h) slice is an independent problem: permuting heads permutes the output bit-exactly
+    perm = torch.randperm(32, device=dev)
+    out_p, lse_p = tfa.flash_attention_v2_cutlass(q[:, perm].contiguous(), k[:, perm].contiguous(), v[:, perm].contiguous(), True, sc)
+    assert torch.equal(out_p, out[:, perm]) and torch.equal(lse_p, lse[:, perm])
+    # (2) causal prefix: the first n rows depend only on the first n keys -> bit-identical to the truncated problem
+    n = 1536
+    out_t, lse_t = tfa.flash_attention_v2_cutlass(q[:, :, :n].contiguous(), k[:, :, :n].contiguous(), v[:, :, :n].contiguous(), True, sc)
+    assert torch.equal(out_t, out[:, :, :n]) and torch.equal(lse_t, lse[:, :, :n])
+    # (3) rows of softmax sum to one: V == 1 gives O == 1 up to the 16-bit rounding of P
+    ones = torch.ones_like(v)
+    out_1, _ = tfa.flash_attention_v2_cutlass(q, k, ones, True, sc)
+    assert (out_1.float() - 1.0).abs().max().item() <= 2 ** -7
+    # (4) shifting every score of a row by a constant leaves O unchanged and moves LSE by that constant:
+    #     k -> k + c*e0 with q[...,0] fixed to 1 adds scale*c to every score
+    q2 = q.clone(); q2[..., 0] = 1.0
+    k2 = k.clone(); k2[..., 0] = 0.0
+    k3 = k2.clone(); k3[..., 0] = 2.0
+    o_a, l_a = tfa.flash_attention_v2_cutlass(q2, k2, v, True, sc)
+    o_b, l_b = tfa.flash_attention_v2_cutlass(q2, k3, v, True, sc)
+    assert (l_b - l_a - 2.0 * sc).abs().max().item() <= 1e-3
+    assert (o_a.float() - o_b.float()).abs().max().item() <= 2e-2
+
+
+def test_long_context_cfg4_properties(tfa, dev):
+    # config 4: B=1 H=16 N=16384 D=128 bf16, non-causal; V == 1 -> O == 1, and head independence
+    q, k, v = _headline(dev, B=1, H=16, N=16384, seed=3)
+    sc = 1.0 / math.sqrt(128)
+    out, lse = tfa.flash_attention_v2_cutlass(q, k, v, False, sc)
+    out_1, lse_1 = tfa.flash_attention_v2_cutlass(q, k, torch.ones_like(v), False, sc)
+    assert (out_1.float() - 1.0).abs().max().item() <= 2 ** -7
+    assert torch.equal(lse, lse_1)
+    out_h, lse_h = tfa.flash_attention_v2_cutlass(q[:, 5:6].contiguous(), k[:, 5:6].contiguous(), v[:, 5:6].contiguous(), False, sc)
+    assert torch.equal(out_h, out[:, 5:6]) and torch.equal(lse_h, lse[:, 5:6])
+    # non-causal: a permutation of the keys (with their values) leaves the result unchanged up to rounding
+    perm = torch.randperm(16384, device=dev)
+    out_k, lse_k = tfa.flash_attention_v2_cutlass(q[:, :2].contiguous(), k[:, :2, perm].contiguous(), v[:, :2, perm].contiguous(), False, sc)
+    assert (lse_k - lse[:, :2]).abs().max().item() <= 1e-3
+    assert (out_k.float() - out[:, :2].float()).abs().max().item() <= 1e-2 * out.float().abs().max().item() + 2 ** -9
+
+
+def test_strided_bnhd_matches_bhnd(tfa, oracle, dev):
+    from tiny_flash_attention_amd import ops
+
+    q, k, v = oracle.make_inputs(2, 8, 384, 128, torch.bfloat16, seed=5, Hk=2)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    o_bhnd, l_bhnd = ops.flash_attn_fwd(qd, kd, vd, True, 0.09)
+    qt, kt, vt = (t.transpose(1, 2).contiguous() for t in (qd, kd, vd))     # (B,N,H,D) storage
+    o_bnhd, l_bnhd = ops.flash_attn_fwd(qt, kt, vt, True, 0.09, layout="bnhd")
+    assert torch.equal(o_bnhd.transpose(1, 2), o_bhnd) and torch.equal(l_bnhd, l_bhnd)

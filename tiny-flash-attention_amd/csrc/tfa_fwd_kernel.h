@@ -85,16 +85,27 @@ static __device__ __forceinline__ s16x4 lds_read_tr16_b64(const char* p) {
 
 static __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// max over the two half-waves (lane l and lane l^32) — one v_permlane32_swap + one v_max.
+// Exchange between the two half-waves (lane l <-> lane l^32) with ONE v_permlane32_swap.
+// After `v_permlane32_swap a, b` (a: upper half <-> b: lower half) with a == b == x on entry:
+//   a = {x_lo, x_lo},  b = {x_hi, x_hi}   in lanes {0-31, 32-63}.
+// Written as inline asm: with identical operands hipcc (ROCm 7.2) folds the builtin's two results
+// into one register and the reduction silently degenerates to max(x,x) / x+x.  The s_nop covers the
+// "VALU write -> v_permlane read" hazard (2 wait states), which nothing pads inside an asm statement.
+static __device__ __forceinline__ void half_swap(float x, float& lo, float& hi) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  lo = a;
+  hi = b;
+}
 static __device__ __forceinline__ float pair_max(float x) {
-  unsigned u = __builtin_bit_cast(unsigned, x);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  float lo, hi;
+  half_swap(x, lo, hi);
+  return fmaxf(lo, hi);
 }
 static __device__ __forceinline__ float pair_sum(float x) {
-  unsigned u = __builtin_bit_cast(unsigned, x);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  float lo, hi;
+  half_swap(x, lo, hi);
+  return lo + hi;
 }
 
 // ---- LDS layouts -------------------------------------------------------------------------
