@@ -129,6 +129,12 @@ int tfa_get_variant(void);
 int tfa_num_variants(void);
 const char* tfa_variant_name(int variant);
 
+/* Debug/profiling: when dev_buf != NULL every workgroup of subsequent launches writes 8 x uint64
+ * {t_start, t_after_prologue, t_after_loop, t_end (shader cycles), n_kv_tiles, XCC_ID, HW_ID,
+ * (bh<<32)|query_block} at dev_buf[8*workgroup_id ...]; the buffer must hold 64 B per workgroup
+ * (tfa_fwd_plan reports the grid).  NULL (default) disables it. */
+int tfa_debug_set_trace(void* dev_buf);
+
 /* Algorithmic work of *p: flops = 4*B*H*Nq*Nk*D (x1/2 when causal, the reference's
  * convention) and bytes = Q+K+V read once + O written once (+LSE). */
 int tfa_fwd_work(const tfa_fwd_params* p, double* flops, double* bytes);

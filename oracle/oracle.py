@@ -127,40 +127,56 @@ def sdpa_reference(q, k, v, is_causal, softmax_scale):
     return torch.matmul(p, v32), lse
 
 
-def tiled_emulation(q, k, v, is_causal, softmax_scale, block_m=32, block_n=64):
-    """Restatement of flash_attention_v2 in flash_attention_py/main_torch_only.py:160-270 for
-    (B,H,N,D) inputs: Q-outer / KV-inner tile loop, causal mask per tile (:231-237), scale (:239),
-    running max/sum (:240-257), ``local_score.to(q.dtype) @ v_tile`` (:260), final divide (:267).
-    Returns fp32 (the reference stores into a q-dtype tensor; round with ``.to(q.dtype)``)."""
-    B, H, N, D = q.shape
-    assert k.shape == q.shape and N % block_m == 0 and N % block_n == 0, "Simple for now (main_torch_only.py:196)"
-    dt = q.dtype
-    out = torch.empty((B, H, N, D), dtype=torch.float32)
-    qf, kf, vf = q.cpu(), k.cpu(), v.cpu()
-    for q_start in range(0, N, block_m):
-        q_tile = qf[:, :, q_start:q_start + block_m, :]
-        g_score = torch.zeros((B, H, block_m, D), dtype=torch.float32)
-        g_sum = torch.zeros((B, H, block_m, 1), dtype=torch.float32)
-        g_max = torch.full((B, H, block_m, 1), -math.inf, dtype=torch.float32)
-        for kv_start in range(0, N, block_n):
-            k_tile = kf[:, :, kv_start:kv_start + block_n, :]
-            v_tile = vf[:, :, kv_start:kv_start + block_n, :]
-            qk = torch.matmul(q_tile.float(), k_tile.float().transpose(2, 3))  # 16-bit products, fp32 accumulate
-            if is_causal:
-                rows = q_start + torch.arange(block_m)[:, None]
-                cols = kv_start + torch.arange(block_n)[None, :]
-                qk = qk.masked_fill(cols > rows, -math.inf)
-            qk = qk * softmax_scale
-            local_max = qk.max(dim=-1, keepdim=True).values
-            new_max = torch.maximum(local_max, g_max)
-            safe_max = torch.where(torch.isinf(new_max), torch.zeros_like(new_max), new_max)
-            rescale = torch.exp(g_max - safe_max)
-            local_score = torch.exp(qk - safe_max)
-            g_sum = g_sum * rescale + local_score.sum(dim=-1, keepdim=True)
-            g_score = g_score * rescale + torch.matmul(local_score.to(dt).float(), v_tile.float())
-            g_max = new_max
-        out[:, :, q_start:q_start + block_m, :] = g_score / g_sum
+def tiled_emulation(q, k, v, is_causal, softmax_scale, block_n=64, p_dtype=None, return_lse=False):
+    """Restatement of the reference's torch tile loop flash_attention_v2
+    (flash_attention_py/main_torch_only.py:160-270) generalised to (B,H,Nq,D) x (B,Hk,Nk,D):
+    KV-inner loop over tiles of ``block_n`` keys (the reference's block_n = 64, :196), causal
+    mask per tile (:231-237, with the C path's Nq != Nk offset attn.cpp:121-124), scale (:239),
+    running max / sum (:240-257), ``local_score.to(q.dtype) @ v_tile`` (:260), final divide (:267).
+    Rows are independent, so the Q-outer loop is vectorised (block_m does not change any value).
+    The 16-bit rounding of P happens against the RUNNING max of each tile — the same rounding
+    points as the GPU kernel, whose KV tile is also 64 keys.  Returns fp32 O (and LSE)."""
+    B, H, Nq, D = q.shape
+    _, Hk, Nk, _ = k.shape
+    dt = q.dtype if p_dtype is None else p_dtype
+    qf = q.detach().cpu().float()
+    kf = k.detach().cpu().float()
+    vf = v.detach().cpu().float()
+    if Hk != H:
+        kf = kf.repeat_interleave(H // Hk, dim=1)
+        vf = vf.repeat_interleave(H // Hk, dim=1)
+    g_score = torch.zeros((B, H, Nq, D), dtype=torch.float32)
+    g_sum = torch.zeros((B, H, Nq, 1), dtype=torch.float32)
+    g_max = torch.full((B, H, Nq, 1), -math.inf, dtype=torch.float32)
+    rows = torch.arange(Nq)[:, None] + (Nk - Nq)
+    for kv_start in range(0, Nk, block_n):
+        k_tile = kf[:, :, kv_start:kv_start + block_n, :]
+        v_tile = vf[:, :, kv_start:kv_start + block_n, :]
+        qk = torch.matmul(qf, k_tile.transpose(2, 3))          # 16-bit products, fp32 accumulate
+        if is_causal:
+            cols = kv_start + torch.arange(k_tile.shape[2])[None, :]
+            qk = qk.masked_fill(cols > rows, -math.inf)
+        qk = qk * softmax_scale
+        local_max = qk.max(dim=-1, keepdim=True).values
+        new_max = torch.maximum(local_max, g_max)
+        safe_max = torch.where(torch.isinf(new_max), torch.zeros_like(new_max), new_max)
+        rescale = torch.exp(g_max - safe_max)
+        local_score = torch.exp(qk - safe_max)
+        g_sum = g_sum * rescale + local_score.sum(dim=-1, keepdim=True)
+        g_score = g_score * rescale + torch.matmul(local_score.to(dt).float(), v_tile)
+        g_max = new_max
+    empty = g_sum == 0
+    out = torch.where(empty, torch.zeros_like(g_score), g_score / torch.where(empty, torch.ones_like(g_sum), g_sum))
+    if return_lse:
+        lse = torch.where(empty, torch.full_like(g_sum, math.inf), g_max + torch.log(g_sum)).squeeze(-1)
+        return out, lse
     return out
+
+
+def abs_weighted(q, k, v, is_causal, softmax_scale):
+    """A[i,d] = sum_j P[i,j] |v[j,d]| — the non-cancelling magnitude of each output element; the
+    natural scale for error bounds on O (|O| <= A, with equality when no cancellation)."""
+    return exact64(q, k, v.abs(), is_causal, softmax_scale)
 
 
 _ref_mod = None

@@ -53,7 +53,7 @@ def test_golden_torch_only_bf16(oracle, causal):
     torch.testing.assert_close(exact, want_safe, atol=1e-2, rtol=1e-2)
     torch.testing.assert_close(exact, want_v2, atol=1e-2, rtol=1e-2)
     # our restatement of the tile loop reproduces the reference's tile loop output to bf16 rounding
-    emu = oracle.tiled_emulation(qb.contiguous(), kb.contiguous(), vb.contiguous(), bool(causal), sc, 32, 64)
+    emu = oracle.tiled_emulation(qb.contiguous(), kb.contiguous(), vb.contiguous(), bool(causal), sc, 64)
     assert (emu.to(torch.bfloat16).float() - want_v2).abs().max() <= 2 ** -7  # <= 1 bf16 ulp at |o|<2
 
 
@@ -103,3 +103,20 @@ def test_rounding_helpers(oracle):
     b = oracle.exact64(q, k, v, False, 0.125, p_round=torch.bfloat16)
     d = (a - b).abs().max().item()
     assert 0 < d < 2e-3  # rounding P moves the result, but only at the 2^-9 relative level
+
+
+def test_tiled_emulation_general_shapes(oracle):
+    # the tile-loop restatement agrees with the exact oracle up to the 16-bit rounding of P,
+    # including GQA, Nq != Nk (both directions), ragged tiles and empty rows
+    for (Nq, Nk, causal) in ((100, 333, False), (128, 384, True), (384, 128, True), (77, 77, True)):
+        q, k, v = oracle.make_inputs(1, 4, Nq, 64, torch.bfloat16, seed=3, Hk=2, Nk=Nk)
+        e, le = oracle.tiled_emulation(q, k, v, causal, 0.125, return_lse=True)
+        x, lx = oracle.exact64(q, k, v, causal, 0.125, p_round=torch.bfloat16, return_lse=True)
+        a = oracle.abs_weighted(q, k, v, causal, 0.125)
+        assert bool(((e - x).abs() <= 2 ** -8 * a + 1e-6).all())      # worst-case P-rounding bound
+        fin = torch.isfinite(lx)
+        assert bool((torch.isfinite(le) == fin).all())
+        assert (le[fin] - lx[fin]).abs().max().item() < 1e-5
+        # with P left in fp32 the two formulations coincide to fp32 round-off
+        e32 = oracle.tiled_emulation(q, k, v, causal, 0.125, p_dtype=torch.float32)
+        assert (e32 - oracle.exact64(q, k, v, causal, 0.125)).abs().max().item() < 5e-6

@@ -2,16 +2,21 @@
 against the CPU oracle on identical seeded inputs, against the reference-generated golden
 fixtures, and — at BASELINE.json's full sizes — through size-independent properties.
 
-Tolerances (floating point; stated here once):
-  * 16-bit outputs vs the fp64 oracle: |d| <= 1e-2 absolute — the reference's own bar
-    (flash_attention_cutlass/test.py:87, flash_attention_c/test.py:82-83) — AND
-    |d| <= 1 ulp(out dtype) + 1e-3*max|ref|  (tighter: the result is the correctly rounded value
-    up to the fp32-path error below).
-  * fp32-output debug path vs the fp64 oracle that rounds P exactly like the kernel's contract
-    (oracle.exact64(p_round=dtype)): BASELINE.json's rtol=1e-3, as
-    |d| <= 1e-3*|ref| + 1e-3*max|ref|  (the additive term covers cancellation in sum_j P_ij v_j,
-    where a relative bound is meaningless; it is 1e-3 of the output scale).
-  * LSE (fp32) vs oracle: |d| <= 1e-3 (reference has no LSE test; values are O(ln N)).
+Tolerances (floating point; stated here once, used by check()):
+  (T1) 16-bit outputs vs the fp64 oracle: |d| <= 1e-2 absolute — the reference's own bar
+       (flash_attention_cutlass/test.py:87, flash_attention_c/test.py:82-83).
+  (T2) fp32-output debug path vs the oracle with the SAME rounding points (oracle.tiled_emulation,
+       the reference's tile loop main_torch_only.py:160-270 with its block_n=64 = the kernel's KV
+       tile): BASELINE.json's rtol=1e-3, |d| <= 1e-3*|ref| + 1e-4*A (A = sum_j P_ij|v_jd|, the element's
+       non-cancelling magnitude: where the sum cancels, |ref| << A and a bound relative to |ref| alone is
+       meaningless).  A P value that sits
+       within fp32 round-off of a 16-bit rounding boundary may round the other way (exp2-based vs
+       exp-based exponent): at most 1e-4 of the elements may exceed (T2), and every element obeys (T3).
+  (T3) fp32-output path vs the fp64 oracle, rigorous bound from rounding P to 16 bit:
+       |d| <= 2^-8 * A + 1e-6 (bf16) or 2^-11 * A + 1e-6 (fp16), A[i,d] = sum_j P_ij |v_jd|.
+  (T4) 16-bit outputs vs the same-rounding-points oracle: the final RNE rounding adds half an ulp to
+       (T2): |d| <= 0.5*ulp16(ref) + 1e-3*|ref| + 1e-4*A (same 1e-4 outlier allowance).
+  (T5) LSE (fp32) vs oracle: |d| <= 1e-4; the +inf pattern of empty rows must match exactly.
 """
 import math
 
@@ -39,22 +44,33 @@ def tfa():
     _lib.set_variant(-1)
 
 
-def check(out16, out32, lse, ref, lse_ref, dtype):
-    scale = ref.abs().max().item()
-    d16 = (out16.float().cpu() - ref).abs()
-    assert d16.max().item() <= 1e-2, f"16-bit out: max|d|={d16.max().item():.3e} > reference bar 1e-2"
-    bound16 = ulp16(ref, dtype) + 1e-3 * scale
-    assert bool((d16 <= bound16).all()), f"16-bit out exceeds 1 ulp + 1e-3*scale: worst {(d16 - bound16).max().item():.3e}"
+def check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype):
+    """q,k,v: CPU tensors (B,H,Nq,D)/(B,Hk,Nk,D) of `dtype`; out*/lse: kernel results."""
+    emu, lse_e = oracle.tiled_emulation(q, k, v, causal, sc, 64, return_lse=True)
+    exact, lse_x = oracle.exact64(q, k, v, causal, sc, return_lse=True)
+    A = oracle.abs_weighted(q, k, v, causal, sc)
+    o16 = out16.float().cpu()
+    assert bool(torch.isfinite(o16).all())
+    d16 = (o16 - exact).abs().max().item()
+    assert d16 <= 1e-2, f"(T1) 16-bit out: max|d|={d16:.3e} > reference bar 1e-2"
+    b16 = 0.5 * ulp16(emu, dtype) * (1 + 1e-3) + 1e-3 * emu.abs() + 1e-4 * A
+    frac16 = ((o16 - emu).abs() > b16).float().mean().item()
+    assert frac16 <= 1e-4, f"(T4) 16-bit out: {frac16:.2e} of elements beyond half an ulp + rtol 1e-3"
     if out32 is not None:
-        d32 = (out32.cpu() - ref).abs()
-        bound32 = 1e-3 * ref.abs() + 1e-3 * scale
-        assert bool((d32 <= bound32).all()), f"fp32 out: rtol=1e-3 violated, worst excess {(d32 - bound32).max().item():.3e}"
+        o32 = out32.cpu()
+        d = (o32 - emu).abs()
+        viol = d > 1e-3 * emu.abs() + 1e-4 * A
+        frac = viol.float().mean().item()
+        assert frac <= 1e-4, f"(T2) rtol=1e-3 violated by {frac:.2e} of elements (max|d|={d.max().item():.3e})"
+        eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        dx = (o32 - exact).abs()
+        assert bool((dx <= eps * A + 1e-6).all()), f"(T3) exceeds the P-rounding bound: worst excess {(dx - eps * A).max().item():.3e}"
     if lse is not None:
-        fin = torch.isfinite(lse_ref)
-        assert bool((torch.isinf(lse.cpu()) == ~fin).all()), "LSE +inf pattern (empty rows) differs"
+        fin = torch.isfinite(lse_x)
+        assert bool((torch.isinf(lse.cpu()) == ~fin).all()), "(T5) LSE +inf pattern (empty rows) differs"
         if fin.any():
-            dl = (lse.cpu()[fin] - lse_ref[fin]).abs().max().item()
-            assert dl <= 1e-3, f"LSE max|d|={dl:.3e}"
+            dl = (lse.cpu()[fin] - lse_x[fin]).abs().max().item()
+            assert dl <= 1e-4, f"(T5) LSE max|d|={dl:.3e}"
 
 
 def run_case(tfa, oracle, dev, dtype, B, H, N, D, causal, Hk=None, Nk=None, seed=0, scale=None, dist="normal"):
@@ -62,12 +78,11 @@ def run_case(tfa, oracle, dev, dtype, B, H, N, D, causal, Hk=None, Nk=None, seed
 
     q, k, v = oracle.make_inputs(B, H, N, D, dtype, seed=seed, Hk=Hk, Nk=Nk, dist=dist)
     sc = 1.0 / math.sqrt(D) if scale is None else scale
-    ref, lse_ref = oracle.exact64(q, k, v, causal, sc, p_round=dtype, return_lse=True)
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
     out16, lse = ops.flash_attn_fwd(qd, kd, vd, causal, sc)
     out32, _ = ops.flash_attn_fwd(qd, kd, vd, causal, sc, out_f32=True)
     torch.cuda.synchronize()
-    check(out16, out32, lse, ref, lse_ref, dtype)
+    check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype)
 
 
 SHAPES = [
@@ -86,7 +101,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", list(range(11)))
 @pytest.mark.parametrize("dtype,B,H,N,D,causal", SHAPES)
 def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
     from tiny_flash_attention_amd import _lib
@@ -192,7 +207,7 @@ def test_inputs_not_modified_and_deterministic(tfa, oracle, dev):
 # ---------------------------------------------------------------------------------------------
 # data-dependent branch: the exact "max unchanged -> skip the O rescale" path and late max jumps
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 5, 7, 10])
 def test_late_max_jump_spike(tfa, oracle, dev, variant):
     from tiny_flash_attention_amd import _lib, ops
 
@@ -204,10 +219,9 @@ def test_late_max_jump_spike(tfa, oracle, dev, variant):
     _lib.set_variant(variant)
     try:
         for causal in (False, True):
-            ref, lse_ref = oracle.exact64(q, k, v, causal, sc, p_round=torch.bfloat16, return_lse=True)
             out16, lse = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc)
             out32, _ = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc, out_f32=True)
-            check(out16, out32, lse, ref, lse_ref, torch.bfloat16)
+            check(oracle, out16, out32, lse, q, k, v, causal, sc, torch.bfloat16)
     finally:
         _lib.set_variant(-1)
 
@@ -230,8 +244,7 @@ def test_headline_cfg3_sampled_heads_vs_oracle(tfa, oracle, dev):
     assert bool(torch.isfinite(out.float()).all())
     for (b, h) in ((0, 0), (3, 31)):
         sl = lambda t: t[b:b + 1, h:h + 1].cpu()
-        ref, lse_ref = oracle.exact64(sl(q), sl(k), sl(v), True, sc, p_round=torch.bfloat16, return_lse=True)
-        check(sl(out), None, sl(lse), ref, lse_ref, torch.bfloat16)
+        check(oracle, sl(out), None, sl(lse), sl(q), sl(k), sl(v), True, sc, torch.bfloat16)
 
 
 def test_headline_properties(tfa, dev):

@@ -22,6 +22,7 @@ SYMBOLS = (
     "tfa_num_variants",
     "tfa_variant_name",
     "tfa_fwd_work",
+    "tfa_debug_set_trace",
 )
 
 
@@ -92,6 +93,8 @@ def lib():
     L.tfa_num_variants.restype = C.c_int
     L.tfa_variant_name.restype = C.c_char_p
     L.tfa_variant_name.argtypes = [C.c_int]
+    L.tfa_debug_set_trace.restype = C.c_int
+    L.tfa_debug_set_trace.argtypes = [C.c_void_p]
     L.tfa_fwd_work.restype = C.c_int
     L.tfa_fwd_work.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = L

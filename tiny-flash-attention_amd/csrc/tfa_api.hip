@@ -22,6 +22,7 @@ template <> hipError_t launch_fwd<_Float16, 128>(const KArgs&, bool, bool, int, 
 namespace {
 
 int g_variant = -1;   // -1 = automatic
+unsigned long long* g_trace = nullptr;   // debug: per-workgroup cycle stamps (tfa_debug_set_trace)
 
 int pick_variant(const tfa_fwd_params* p) {
   if (g_variant >= 0) return g_variant;
@@ -48,7 +49,8 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   if (p->B <= 0 || p->H <= 0 || p->Hk <= 0 || p->Nq <= 0 || p->Nk <= 0) return TFA_ERR_SHAPE;
   if (p->H % p->Hk != 0) return TFA_ERR_SHAPE;
   if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
-  if (variant < 0 || variant >= tfa::kNumVariants) return TFA_ERR_VARIANT;
+  const bool ablate = variant >= 100 && variant < 100 + 256;   // timing-only ablations (debug)
+  if (!ablate && (variant < 0 || variant >= tfa::kNumVariants)) return TFA_ERR_VARIANT;
   const int esz = 2, osz = (p->out_dtype == TFA_F32) ? 4 : 2;
   const int64_t* st[4] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride};
   for (int t = 0; t < 4; ++t) {
@@ -74,11 +76,13 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   if (!slice_bytes(p->Nk, a->vs_n, p->D, esz, &a->v_bytes)) return TFA_ERR_STRIDE;
   if (!slice_bytes(p->Nq, a->os_n, p->D, osz, &a->o_bytes)) return TFA_ERR_STRIDE;
   a->scale = p->softmax_scale;
+  a->trace = g_trace;
   a->scale_log2 = p->softmax_scale * 1.4426950408889634f;
-  const int bm = tfa::block_m_of(variant);
+  const int bm = ablate ? 256 : tfa::block_m_of(variant);
   a->nmb = (p->Nq + bm - 1) / bm;
+  a->nwork = (p->is_causal && (ablate || tfa::pairs_causal(variant))) ? (a->nmb + 1) / 2 : a->nmb;
   const int64_t nbh = (int64_t)p->B * p->H;
-  if (nbh * a->nmb >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
+  if (nbh * a->nwork >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
   a->nbh = (int)nbh;
   return TFA_OK;
 }
@@ -190,11 +194,12 @@ int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, f
 }
 
 int tfa_set_variant(int variant) {
-  if (variant < -1 || variant >= tfa::kNumVariants) return TFA_ERR_VARIANT;
+  if (variant < -1 || (variant >= tfa::kNumVariants && (variant < 100 || variant >= 356))) return TFA_ERR_VARIANT;
   g_variant = variant;
   return TFA_OK;
 }
 int tfa_get_variant(void) { return g_variant; }
+int tfa_debug_set_trace(void* dev_buf) { g_trace = reinterpret_cast<unsigned long long*>(dev_buf); return TFA_OK; }
 int tfa_num_variants(void) { return tfa::kNumVariants; }
 const char* tfa_variant_name(int variant) {
   if (variant < 0 || variant >= tfa::kNumVariants) return "auto";

@@ -2,24 +2,33 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "tfa_fwd_kernel.h"
+#include "tfa_fwd_kernel_pp.h"
 
 namespace tfa {
 
 struct Variant {
   const char* name;
-  int nw;   // waves per workgroup (32 query rows each)
+  int nw;   // waves per workgroup
   int vf;   // VF_* flags
+  int rb;   // 32-row query blocks per wave
 };
 
 // Keep in sync with the switch in tfa_fwd_inst.inc
 static const Variant kVariants[] = {
-    {"w8-gatherV (bring-up: 16-bit LDS gathers for V, no transpose read)", 8, 0},
-    {"w8-trV (8 waves x 32 rows, ds_read_b64_tr_b16 for V)", 8, VF_TRREAD},
-    {"w4-trV (4 waves x 32 rows, 2 workgroups/CU)", 4, VF_TRREAD},
-    {"w8-trV-alwaysrescale (no exact alpha==1 skip)", 8, VF_TRREAD | VF_NOSKIP},
+    {"w8-gatherV (bring-up: 16-bit LDS gathers for V, no transpose read)", 8, 0, 1},
+    {"w8-trV (8 waves x 32 rows, ds_read_b64_tr_b16 for V)", 8, VF_TRREAD, 1},
+    {"w4-trV (4 waves x 32 rows, 2 workgroups/CU)", 4, VF_TRREAD, 1},
+    {"w8-trV-alwaysrescale (no exact alpha==1 skip)", 8, VF_TRREAD | VF_NOSKIP, 1},
+    {"w8-trV-pair (causal blocks paired heavy+light per workgroup)", 8, VF_TRREAD | VF_PAIR, 1},
+    {"w8-trV-pair-kpre-vpre (K and V fragments prefetched to registers)", 8, VF_TRREAD | VF_PAIR | VF_KPRE | VF_VPRE, 1},
+    {"w4-trV-pair-kpre-vpre", 4, VF_TRREAD | VF_PAIR | VF_KPRE | VF_VPRE, 1},
+    {"w8-trV-pair-vpre", 8, VF_TRREAD | VF_PAIR | VF_VPRE, 1},
+    {"pp8-pair-vpre0 (ping-pong: two wave groups half a tile apart; V fragments read in the 2nd half)", 8, VF_PP | VF_PAIR | (0 << VF_VPRE_SHIFT), 1},
+    {"pp8-pair-vpre2 (ping-pong; V fragments of 2 d-tiles read ahead in the 1st half)", 8, VF_PP | VF_PAIR | (2 << VF_VPRE_SHIFT), 1},
+    {"pp8-pair-vpre4 (ping-pong; all V fragments read ahead in the 1st half)", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT), 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 1;
+constexpr int kDefaultVariant = 7;
 
 struct LaunchGeom {
   int grid, block, lds;
@@ -28,6 +37,7 @@ struct LaunchGeom {
 template <typename T, int D>
 hipError_t launch_fwd(const KArgs& a, bool causal, bool f32out, int variant, hipStream_t stream, LaunchGeom* geom, bool dry);
 
-static inline int block_m_of(int variant) { return kVariants[variant].nw * 32; }
+static inline int block_m_of(int variant) { return kVariants[variant].nw * 32 * kVariants[variant].rb; }
+static inline bool pairs_causal(int variant) { return (kVariants[variant].vf & VF_PAIR) != 0; }
 
 }  // namespace tfa
