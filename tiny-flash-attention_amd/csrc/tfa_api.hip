@@ -26,8 +26,11 @@ unsigned long long* g_trace = nullptr;   // debug: per-workgroup cycle stamps (t
 
 int pick_variant(const tfa_fwd_params* p) {
   if (g_variant >= 0) return g_variant;
-  (void)p;
-  return tfa::kDefaultVariant;
+  if (!p) return tfa::kDefaultVariant;
+  // 256-row query blocks need >= ~2 workgroups per CU to fill 256 CUs; small problems
+  // (e.g. BASELINE config 2: B4 H8 N1024 -> 128 blocks) take the 128-row / 4-wave kernel instead.
+  const long long blocks256 = (long long)p->B * p->H * ((p->Nq + 255) / 256);
+  return blocks256 < 512 ? tfa::kSmallGridVariant : tfa::kDefaultVariant;
 }
 
 // extent in bytes of one (b,h) slice: rows 0..N-1 at row stride, D contiguous elements each

@@ -1,0 +1,335 @@
+// tfa_fwd_kernel_dma.h — the forward tile loop with K/V tiles brought into LDS by LDS-DMA
+// (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction) instead of global->VGPR->ds_write.
+//
+// Why: in the register-staged kernel (tfa_fwd_kernel.h) the staging costs ~13 % of the tile time
+// (ablation: tools/ablate.py, NOSTAGE): 4 ds_write_b128 per thread per tile occupy the LDS store
+// path and the single register set limits the global prefetch distance to one tile.  Here
+//   * no staging VGPRs and no ds_write: the DMA writes LDS directly;
+//   * three LDS tile buffers: tile j is computed while tile j+1 is landed/landing and tile j+2 is
+//     in flight — two tiles of latency tolerance, waits are COUNTED (`s_waitcnt vmcnt(N)`, never a
+//     drain while a younger tile is in flight) and barriers are raw `s_barrier`;
+//   * an LDS-DMA piece lands lane-linear (wave-uniform base + lane*16), so the K chunk swizzle and
+//     the V sub-tile order are applied to the per-lane SOURCE address; the LDS images are exactly
+//     those of tfa_fwd_kernel.h (same fragment reads).
+// Out-of-range rows still read as zeros (buffer descriptor bounds check), so ragged N is unchanged.
+#pragma once
+#include "tfa_fwd_kernel.h"
+
+namespace tfa {
+
+// One LDS-DMA piece: every lane fetches 16 bytes at (descriptor base + voffset) and the wave's
+// 1 KiB lands at LDS byte address lds_addr + lane*16 (M0 = wave-uniform LDS address).
+// Inline asm on purpose: given the builtin, hipcc (ROCm 7.2) orders every later ds_read that may
+// alias behind the DMA with `s_waitcnt vmcnt(0)`, which drains the two-tile-deep pipeline each
+// tile.  Nothing here has a VGPR destination; completion is tracked by the counted vmcnt waits in
+// the tile loop.  `s_nop 4` covers "SALU wrote an SGPR of the descriptor / M0 -> VMEM reads it".
+static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, int voffset) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_addr), "v"(voffset), "s"(rs)
+      : "memory");
+}
+
+template <typename T, int D, int NW, bool CAUSAL, bool F32OUT, int VF>
+__global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
+  using E = Elem<T>;
+  using X8 = typename E::x8;
+  constexpr int BM = NW * 32;
+  constexpr int BN = 64;
+  constexpr int CPR = D / 8;                       // 16-byte chunks per row
+  constexpr int TILE_BYTES = BN * D * 2;           // one K (or V) tile
+  constexpr int NBUF = 3;
+  constexpr int PIECES = TILE_BYTES / 1024;        // 1 KiB DMA pieces per tensor per tile
+  constexpr int PPW = PIECES / NW;                 // pieces per wave per tensor
+  constexpr int DS = D / 16;
+  constexpr int DT = D / 32;
+  constexpr bool PAIR = CAUSAL && (VF & VF_PAIR);
+  static_assert(PPW >= 1 && PPW * NW == PIECES, "tile does not split into whole DMA pieces per wave");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const kl = smem;                           // K buffers 0..2
+  char* const vl = smem + NBUF * TILE_BYTES;       // V buffers 0..2
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
+  if (p.trace) t_start = __builtin_amdgcn_s_memtime();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 31;
+  const int hi = lane >> 5;
+
+  int bh, wi;
+  {
+    const int id = blockIdx.x;
+    if ((p.nbh & 7) == 0) {
+      const int x = id & 7, s = id >> 3;
+      bh = x + 8 * (s / p.nwork);
+      wi = s % p.nwork;
+    } else {
+      bh = id / p.nwork;
+      wi = id % p.nwork;
+    }
+  }
+  const int b = bh / p.H;
+  const int h = bh - b * p.H;
+  const int hk = h / (p.H / p.Hk);
+  const int shift = p.Nk - p.Nq;
+
+  const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
+  const T* kbase = reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h;
+  const T* vbase = reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h;
+  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, p.q_bytes, 0x00020000);
+  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
+  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
+
+  // ---- per-lane DMA source offsets (tile 0); the LDS destination of piece pc is pc*1024 + lane*16
+  int k_src[PPW], v_src[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pc = wave * PPW + i;
+    {  // K: row-major, chunk position c' holds source chunk c' ^ swz(row)
+      const int row = pc * (1024 / (D * 2)) + lane / CPR;
+      const int cpos = lane % CPR;
+      k_src[i] = row * (int)p.ks_n * 2 + ((cpos ^ k_swz<D>(row)) << 4);
+    }
+    {  // V: invert v_lds_off(): LDS offset -> (key, 16-byte chunk)
+      const int o = pc * 1024 + lane * 16;
+      const int sub = o >> 9, R = (o >> 6) & 7, pcs = (o >> 4) & 3;
+      const int dt = sub % DT, sh = sub / DT;
+      const int key = 16 * (sh >> 1) + 4 * (sh & 1) + 8 * (R >> 2) + (R & 3);
+      v_src[i] = key * (int)p.vs_n * 2 + ((dt * 4 + pcs) << 4);
+    }
+  }
+  const int k_tile_stride = BN * (int)p.ks_n * 2;
+  const int v_tile_stride = BN * (int)p.vs_n * 2;
+
+  auto dma_issue = [&](int j, int buf) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;
+      lds_dma16(k_rs, lds_base + buf * TILE_BYTES + pc * 1024, k_src[i] + j * k_tile_stride);
+      lds_dma16(v_rs, lds_base + (NBUF + buf) * TILE_BYTES + pc * 1024, v_src[i] + j * v_tile_stride);
+    }
+  };
+
+  const int k_rd_base = qi * (D * 2);
+  const int k_rd_swz = k_swz<D>(qi);
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
+  const float sc = p.scale_log2;
+  int nt_total = 0;
+
+  const int npass = PAIR ? ((p.nmb - 1 - wi) != wi ? 2 : 1) : 1;
+#pragma nounroll
+  for (int pass = 0; pass < npass; ++pass) {
+    int mb;
+    if (PAIR) mb = pass == 0 ? (p.nmb - 1 - wi) : wi;
+    else mb = CAUSAL ? (p.nmb - 1 - wi) : wi;
+    const int q0 = mb * BM;
+    int kv_end = p.Nk;
+    if (CAUSAL) {
+      const int lim = q0 + BM + shift;
+      kv_end = lim < kv_end ? lim : kv_end;
+    }
+    const int nt = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+    nt_total += nt;
+
+    // ---- prologue: tiles 0 and 1 by DMA, Q fragments to registers, then everything drained
+    if (nt > 0) dma_issue(0, 0);
+    if (nt > 1) dma_issue(1, 1);
+    const int wave_row0 = q0 + wave * 32;
+    const int my_row = wave_row0 + qi;
+    X8 qf[DS];
+    {
+      const int qoff = my_row * (int)p.qs_n * 2 + hi * 16;
+#pragma unroll
+      for (int s = 0; s < DS; ++s) {
+        u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, qoff + s * 32, 0, 0);
+        qf[s] = __builtin_bit_cast(X8, t);
+      }
+    }
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float m_run = -1e30f;
+    float l_run = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));
+    asm volatile("s_barrier" ::: "memory");
+    if (p.trace && pass == 0) t_pro = __builtin_amdgcn_s_memtime();
+
+    const int wave_last_tile = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (nt - 1);
+
+    auto tile_body = [&](int j, int buf) {
+      // tile j+2 goes into the buffer tile j-1 just vacated
+      const bool more = (j + 2 < nt);
+      if (more) dma_issue(j + 2, (buf + 2) % NBUF);
+
+      if (j <= wave_last_tile) {
+        const char* kb = kl + buf * TILE_BYTES;
+        const char* vb = vl + buf * TILE_BYTES;
+
+        f32x16 sacc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+        {
+          X8 kf[DS][2];
+#pragma unroll
+          for (int s = 0; s < DS; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int off = k_rd_base + t * 32 * (D * 2) + (((2 * s + hi) ^ k_rd_swz) << 4);
+              kf[s][t] = __builtin_bit_cast(X8, lds_read_b128(kb, off));
+            }
+#pragma unroll
+          for (int s = 0; s < DS; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) sacc[t] = E::mfma(kf[s][t], qf[s], sacc[t]);
+        }
+
+        s16x8 vfr[DT][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const char* a = vb + v_rd_base + (s * 2 * DT << 9) + (d << 9);
+            s16x4 lo = lds_read_tr16_b64(a);
+            s16x4 hh = lds_read_tr16_b64(a + 256);
+            vfr[d][s] = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+
+        const int key0 = j * BN;
+        bool need_mask = (key0 + BN > p.Nk);
+        if (CAUSAL) need_mask = need_mask || (key0 + BN - 1 > wave_row0 + shift);
+        if (need_mask) {
+          int lim = p.Nk - 1;
+          if (CAUSAL) { const int c = my_row + shift; lim = c < lim ? c : lim; }
+          lim -= key0 + 4 * hi;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ko = 32 * t + (r & 3) + 8 * (r >> 2);
+              if (ko > lim) sacc[t][r] = -INFINITY;
+            }
+        }
+
+        float mloc = sacc[0][0];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[t][r]);
+        mloc = pair_max(mloc);
+        const float m_new = fmaxf(m_run, mloc);
+        const bool changed = (m_new != m_run);
+        if (__any(changed)) {
+          const float alpha = fast_exp2((m_run - m_new) * sc);
+          l_run *= alpha;
+#pragma unroll
+          for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        }
+        m_run = m_new;
+        const float msc = m_new * sc;
+        X8 pk[4];
+        float lsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = fast_exp2(fmaf(sacc[t][r], sc, -msc));
+            lsum[r & 3] += e;
+            pk[t * 2 + (r >> 3)][r & 7] = (T)e;
+          }
+        l_run += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int d = 0; d < DT; ++d)
+            oacc[d] = E::mfma(__builtin_bit_cast(X8, vfr[d][s]), pk[s], oacc[d]);
+      }
+
+      // tile j+1 must have landed (this wave's pieces; the barrier covers everyone else's), and
+      // every wave must be done reading tile j before tile j+3 overwrites it.  Counted wait: the
+      // 2*PPW pieces of tile j+2 issued above may stay in flight.
+      if (more) {
+        if (PPW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (PPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    for (int j = 0; j < nt; j += 3) {
+      tile_body(j, 0);
+      if (j + 1 < nt) tile_body(j + 1, 1);
+      if (j + 2 < nt) tile_body(j + 2, 2);
+    }
+    if (p.trace && pass == 0) t_loop = __builtin_amdgcn_s_memtime();
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    const float l_tot = pair_sum(l_run);
+    const bool empty = !(l_tot > 0.f);
+    const float inv = empty ? 1.f : 1.f / l_tot;
+    if (p.lse != nullptr && hi == 0 && my_row < p.Nq) {
+      const float lse = empty ? INFINITY : (m_run * p.scale + __builtin_amdgcn_logf(l_tot) * 0.6931471805599453f);
+      p.lse[(long long)bh * p.Nq + my_row] = lse;
+    }
+    if (F32OUT) {
+      float* obase = reinterpret_cast<float*>(p.o) + b * p.os_b + h * p.os_h;
+      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      const int ooff = my_row * (int)p.os_n * 4 + hi * 16;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v4 = {oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, ooff + (d * 32 + g * 8) * 4, 0, 0);
+        }
+    } else {
+      T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
+      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      const int ooff = my_row * (int)p.os_n * 2 + hi * 8;
+      typedef __attribute__((ext_vector_type(4))) T t4;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          t4 v4 = {(T)(oacc[d][4 * g + 0] * inv), (T)(oacc[d][4 * g + 1] * inv), (T)(oacc[d][4 * g + 2] * inv), (T)(oacc[d][4 * g + 3] * inv)};
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, ooff + (d * 32 + g * 8) * 2, 0, 0);
+        }
+    }
+  }
+
+  if (p.trace) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
+      t[0] = t_start; t[1] = t_pro; t[2] = t_loop; t[3] = t_end;
+      t[4] = (unsigned long long)nt_total;
+      t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);
+      t[6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);
+      t[7] = ((unsigned long long)bh << 32) | (unsigned)wi;
+    }
+  }
+}
+
+}  // namespace tfa

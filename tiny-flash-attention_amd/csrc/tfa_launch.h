@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "tfa_fwd_kernel.h"
 #include "tfa_fwd_kernel_pp.h"
+#include "tfa_fwd_kernel_dma.h"
 
 namespace tfa {
 
@@ -26,9 +27,12 @@ static const Variant kVariants[] = {
     {"pp8-pair-vpre0 (ping-pong: two wave groups half a tile apart; V fragments read in the 2nd half)", 8, VF_PP | VF_PAIR | (0 << VF_VPRE_SHIFT), 1},
     {"pp8-pair-vpre2 (ping-pong; V fragments of 2 d-tiles read ahead in the 1st half)", 8, VF_PP | VF_PAIR | (2 << VF_VPRE_SHIFT), 1},
     {"pp8-pair-vpre4 (ping-pong; all V fragments read ahead in the 1st half)", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT), 1},
+    {"dma8-pair (LDS-DMA staging, 3 tile buffers, counted vmcnt; 8 waves)", 8, VF_DMA | VF_PAIR, 1},
+    {"dma4-pair (LDS-DMA staging, 3 tile buffers; 4 waves, 1 workgroup/CU by LDS)", 4, VF_DMA | VF_PAIR, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 7;
+constexpr int kDefaultVariant = 11;     // dma8-pair
+constexpr int kSmallGridVariant = 12;   // dma4-pair (128-row query blocks)
 
 struct LaunchGeom {
   int grid, block, lds;
@@ -38,6 +42,7 @@ template <typename T, int D>
 hipError_t launch_fwd(const KArgs& a, bool causal, bool f32out, int variant, hipStream_t stream, LaunchGeom* geom, bool dry);
 
 static inline int block_m_of(int variant) { return kVariants[variant].nw * 32 * kVariants[variant].rb; }
+static inline bool uses_dma(int variant) { return (kVariants[variant].vf & VF_DMA) != 0; }
 static inline bool pairs_causal(int variant) { return (kVariants[variant].vf & VF_PAIR) != 0; }
 
 }  // namespace tfa

@@ -1,0 +1,62 @@
+"""Batch x head sharding of the forward pass across GPUs (one process per GPU, torch.distributed;
+backend "nccl" is RCCL over xGMI on ROCm).
+
+Every (b,h) pair is an independent attention problem — the reference's grid already treats
+blockIdx.y = b*H + h as independent (flash_attention_cutlass/csrc/flash_attention.cu:382,409,698) —
+so the path shards with NO data-path collective: each rank runs the kernel on a contiguous slab
+of the batch (or of the flattened batch*head axis when B < world).  The only optional collective
+is the "trivial gather" of the output slabs (all_gather_into_tensor).
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous [lo, hi) of `n` units for `rank` of `world` (first n % world ranks get one extra)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_axis(B, H, world):
+    """'batch' when every rank can get whole batches, else 'bh' (flattened batch*head units)."""
+    return "batch" if B >= world and B % world == 0 else "bh"
+
+
+def local_shard(t, world, rank, axis):
+    """Zero-copy view of this rank's slab of a contiguous (B,H,N,D) tensor.
+    axis='batch' -> (B/world, H, N, D); axis='bh' -> (1, n_local, N, D)."""
+    B, H = t.shape[0], t.shape[1]
+    if axis == "batch":
+        lo, hi = shard_bounds(B, world, rank)
+        return t[lo:hi]
+    flat = t.reshape(1, B * H, *t.shape[2:])
+    lo, hi = shard_bounds(B * H, world, rank)
+    return flat[:, lo:hi]
+
+
+def sharded_forward(q, k, v, is_causal, softmax_scale, group=None, gather=True, fn=None):
+    """q,k,v: the FULL (B,H,N,D) tensors, identical on every rank (e.g. broadcast or regenerated from
+    a seed).  Each rank computes its slab; with gather=True every rank returns the full output
+    (all-gather of the slabs, equal slab sizes required), else its local slab.
+    `fn(q,k,v,is_causal,scale) -> out` defaults to the HIP operator; tests inject a CPU function."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if fn is None:
+        fn = lambda a, b_, c, causal, sc: ops.flash_attn_fwd(a, b_, c, causal, sc, return_lse=False)[0]
+    B, H = q.shape[0], q.shape[1]
+    if k.shape[1] != H:
+        raise ValueError("sharded_forward shards whole heads: expand K/V heads (GQA) per rank or shard by batch")
+    axis = shard_axis(B, H, world)
+    ql, kl, vl = (local_shard(t, world, rank, axis) for t in (q, k, v))
+    out_l = fn(ql.contiguous(), kl.contiguous(), vl.contiguous(), is_causal, softmax_scale)
+    if not gather or world == 1:
+        return out_l if world > 1 else out_l.reshape(q.shape)
+    units = B if axis == "batch" else B * H
+    if units % world != 0:
+        raise ValueError("gather needs equal slabs: units % world_size != 0")
+    full = torch.empty(q.shape, dtype=out_l.dtype, device=out_l.device)
+    dist.all_gather_into_tensor(full.view(-1), out_l.contiguous().view(-1), group=group)
+    return full
