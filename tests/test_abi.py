@@ -57,6 +57,9 @@ def test_plan_geometry():
     _lib.set_variant(2)
     st, grid, block, lds = plan(_params(B=4, H=8, Hk=8, Nq=1000, Nk=1000, D=64, dtype=_lib.TFA_F16))
     assert st == 0 and block == 256 and grid == 4 * 8 * 8 and lds == 4 * 64 * 64 * 2
+    _lib.set_variant(11)  # LDS-DMA kernel: three K and three V tile buffers
+    st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
+    assert st == 0 and block == 512 and grid == 4 * 32 * 8 and lds == 6 * 64 * 128 * 2
     _lib.set_variant(4)   # causal blocks paired: ceil(16/2) work items per head
     st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
     assert st == 0 and block == 512 and grid == 4 * 32 * 8
