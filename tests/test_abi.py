@@ -60,6 +60,12 @@ def test_plan_geometry():
     _lib.set_variant(11)  # LDS-DMA kernel: three K and three V tile buffers
     st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
     assert st == 0 and block == 512 and grid == 4 * 32 * 8 and lds == 6 * 64 * 128 * 2
+    _lib.set_variant(15)  # persistent: one workgroup per CU walks the 1024 work items
+    st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
+    assert st == 0 and block == 512 and grid == 256
+    _lib.set_variant(-1)  # automatic: causal N=4096 -> 128-row blocks, two LDS buffers, paired
+    st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
+    assert st == 0 and block == 256 and grid == 4 * 32 * 16 and lds == 4 * 64 * 128 * 2
     _lib.set_variant(4)   # causal blocks paired: ceil(16/2) work items per head
     st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
     assert st == 0 and block == 512 and grid == 4 * 32 * 8

@@ -24,13 +24,30 @@ namespace {
 int g_variant = -1;   // -1 = automatic
 unsigned long long* g_trace = nullptr;   // debug: per-workgroup cycle stamps (tfa_debug_set_trace)
 
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n = prop.multiProcessorCount;
+    else
+      n = 256;   // MI355X; also the answer when no device is visible (dry-run planning on a CPU box)
+  }
+  return n;
+}
+
 int pick_variant(const tfa_fwd_params* p) {
   if (g_variant >= 0) return g_variant;
   if (!p) return tfa::kDefaultVariant;
-  // 256-row query blocks need >= ~2 workgroups per CU to fill 256 CUs; small problems
-  // (e.g. BASELINE config 2: B4 H8 N1024 -> 128 blocks) take the 128-row / 4-wave kernel instead.
+  // Measured on MI355X (tools/ab.py, profiles/): 256-row query blocks (8 waves) are fastest when there
+  // are enough of them to fill 256 CUs and no causal diagonal; 128-row blocks (two 4-wave workgroups per
+  // CU) waste less of the causal diagonal and fill the chip on small problems (BASELINE config 2:
+  // B4 H8 N1024 has only 128 blocks of 256 rows).
   const long long blocks256 = (long long)p->B * p->H * ((p->Nq + 255) / 256);
-  return blocks256 < 512 ? tfa::kSmallGridVariant : tfa::kDefaultVariant;
+  if (blocks256 < 512) return tfa::kSmallGridVariant;
+  if (p->is_causal && p->Nq <= 8192) return tfa::kCausalVariant;
+  return tfa::kDefaultVariant;
 }
 
 // extent in bytes of one (b,h) slice: rows 0..N-1 at row stride, D contiguous elements each
@@ -52,7 +69,7 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   if (p->B <= 0 || p->H <= 0 || p->Hk <= 0 || p->Nq <= 0 || p->Nk <= 0) return TFA_ERR_SHAPE;
   if (p->H % p->Hk != 0) return TFA_ERR_SHAPE;
   if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
-  const bool ablate = variant >= 100 && variant < 100 + 256;   // timing-only ablations (debug)
+  const bool ablate = variant >= 100 && variant < 100 + 512;   // timing-only ablations (debug)
   if (!ablate && (variant < 0 || variant >= tfa::kNumVariants)) return TFA_ERR_VARIANT;
   const int esz = 2, osz = (p->out_dtype == TFA_F32) ? 4 : 2;
   const int64_t* st[4] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride};
@@ -80,6 +97,7 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   if (!slice_bytes(p->Nq, a->os_n, p->D, osz, &a->o_bytes)) return TFA_ERR_STRIDE;
   a->scale = p->softmax_scale;
   a->trace = g_trace;
+  a->grid = num_cus();
   a->scale_log2 = p->softmax_scale * 1.4426950408889634f;
   const int bm = ablate ? 256 : tfa::block_m_of(variant);
   a->nmb = (p->Nq + bm - 1) / bm;
@@ -197,7 +215,7 @@ int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, f
 }
 
 int tfa_set_variant(int variant) {
-  if (variant < -1 || (variant >= tfa::kNumVariants && (variant < 100 || variant >= 356))) return TFA_ERR_VARIANT;
+  if (variant < -1 || (variant >= tfa::kNumVariants && (variant < 100 || variant >= 612))) return TFA_ERR_VARIANT;
   g_variant = variant;
   return TFA_OK;
 }

@@ -36,7 +36,17 @@ static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsi
       : "memory");
 }
 
-template <typename T, int D, int NW, bool CAUSAL, bool F32OUT, int VF>
+constexpr int VF_PERSIST = 2048;   // launch one workgroup per CU and walk the work items (else one item per workgroup)
+constexpr int VF_2BUF = 4096;      // two LDS tile buffers (64 KiB at D=128): two 4-wave workgroups fit one CU
+constexpr int VF_PRIO = 1024;   // s_setprio(1) around the MFMA clusters (experiment, tools/ab.py)
+
+// The kernel walks a STREAM of query blocks: workgroup g takes work items g, g+G, g+2G, ... (G =
+// gridDim.x; a causal work item is the pair {heavy block nmb-1-i, light block i}, so every item costs
+// the same).  With G = number of CUs the launch is persistent: no workgroup turn-around between
+// blocks (measured ~5.2k cycles each), and the next block's first two K/V tiles and its Q fragments are
+// requested BEFORE the current block's epilogue, so its prologue latency hides behind the O stores.
+// With G = number of items the same code degenerates to one item per workgroup.
+template <typename T, int D, int NW, bool CAUSAL, bool F32OUT, int VF, int AB = 0>
 __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
   using E = Elem<T>;
   using X8 = typename E::x8;
@@ -44,7 +54,8 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
   constexpr int BN = 64;
   constexpr int CPR = D / 8;                       // 16-byte chunks per row
   constexpr int TILE_BYTES = BN * D * 2;           // one K (or V) tile
-  constexpr int NBUF = 3;
+  constexpr int NBUF = (VF & VF_2BUF) ? 2 : 3;     // LDS tile buffers; tiles 0..NBUF-2 ahead are in flight
+  constexpr int PD = NBUF - 1;                     // prefetch distance in tiles
   constexpr int PIECES = TILE_BYTES / 1024;        // 1 KiB DMA pieces per tensor per tile
   constexpr int PPW = PIECES / NW;                 // pieces per wave per tensor
   constexpr int DS = D / 16;
@@ -64,30 +75,8 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 31;
   const int hi = lane >> 5;
-
-  int bh, wi;
-  {
-    const int id = blockIdx.x;
-    if ((p.nbh & 7) == 0) {
-      const int x = id & 7, s = id >> 3;
-      bh = x + 8 * (s / p.nwork);
-      wi = s % p.nwork;
-    } else {
-      bh = id / p.nwork;
-      wi = id % p.nwork;
-    }
-  }
-  const int b = bh / p.H;
-  const int h = bh - b * p.H;
-  const int hk = h / (p.H / p.Hk);
   const int shift = p.Nk - p.Nq;
-
-  const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
-  const T* kbase = reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h;
-  const T* vbase = reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h;
-  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, p.q_bytes, 0x00020000);
-  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
-  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
+  const int nitems = p.nbh * p.nwork;
 
   // ---- per-lane DMA source offsets (tile 0); the LDS destination of piece pc is pc*1024 + lane*16
   int k_src[PPW], v_src[PPW];
@@ -110,51 +99,74 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
   const int k_tile_stride = BN * (int)p.ks_n * 2;
   const int v_tile_stride = BN * (int)p.vs_n * 2;
 
-  auto dma_issue = [&](int j, int buf) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int pc = wave * PPW + i;
-      lds_dma16(k_rs, lds_base + buf * TILE_BYTES + pc * 1024, k_src[i] + j * k_tile_stride);
-      lds_dma16(v_rs, lds_base + (NBUF + buf) * TILE_BYTES + pc * 1024, v_src[i] + j * v_tile_stride);
-    }
-  };
-
   const int k_rd_base = qi * (D * 2);
   const int k_rd_swz = k_swz<D>(qi);
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
   const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
   const float sc = p.scale_log2;
-  int nt_total = 0;
 
-  const int npass = PAIR ? ((p.nmb - 1 - wi) != wi ? 2 : 1) : 1;
-#pragma nounroll
-  for (int pass = 0; pass < npass; ++pass) {
-    int mb;
-    if (PAIR) mb = pass == 0 ? (p.nmb - 1 - wi) : wi;
-    else mb = CAUSAL ? (p.nmb - 1 - wi) : wi;
-    const int q0 = mb * BM;
+  // ---- the block stream ----------------------------------------------------------------------
+  struct Blk {
+    int bh, wi, mb, nt;
+    __amdgpu_buffer_rsrc_t q_rs, k_rs, v_rs;
+  };
+  auto decode = [&](int item, int pass, Blk& k) {
+    if ((p.nbh & 7) == 0) {          // heads of one XCD stay together (item & 7 == blockIdx & 7 when G % 8 == 0)
+      const int x = item & 7, s = item >> 3;
+      k.bh = x + 8 * (s / p.nwork);
+      k.wi = s % p.nwork;
+    } else {
+      k.bh = item / p.nwork;
+      k.wi = item % p.nwork;
+    }
+    if (PAIR) k.mb = pass == 0 ? (p.nmb - 1 - k.wi) : k.wi;     // heavy block first, then the light one
+    else k.mb = CAUSAL ? (p.nmb - 1 - k.wi) : k.wi;
     int kv_end = p.Nk;
     if (CAUSAL) {
-      const int lim = q0 + BM + shift;
+      const int lim = k.mb * BM + BM + shift;                    // one past the last key any row of the block sees
       kv_end = lim < kv_end ? lim : kv_end;
     }
-    const int nt = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
-    nt_total += nt;
-
-    // ---- prologue: tiles 0 and 1 by DMA, Q fragments to registers, then everything drained
-    if (nt > 0) dma_issue(0, 0);
-    if (nt > 1) dma_issue(1, 1);
-    const int wave_row0 = q0 + wave * 32;
-    const int my_row = wave_row0 + qi;
-    X8 qf[DS];
-    {
-      const int qoff = my_row * (int)p.qs_n * 2 + hi * 16;
+    k.nt = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+    const int b = k.bh / p.H, h = k.bh - b * p.H, hk = h / (p.H / p.Hk);
+    k.q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h), 0, p.q_bytes, 0x00020000);
+    k.k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h), 0, p.k_bytes, 0x00020000);
+    k.v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h), 0, p.v_bytes, 0x00020000);
+  };
+  auto dma_issue = [&](const Blk& k, int j, int buf) {
 #pragma unroll
-      for (int s = 0; s < DS; ++s) {
-        u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, qoff + s * 32, 0, 0);
-        qf[s] = __builtin_bit_cast(X8, t);
-      }
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;
+      lds_dma16(k.k_rs, lds_base + buf * TILE_BYTES + pc * 1024, k_src[i] + j * k_tile_stride);
+      lds_dma16(k.v_rs, lds_base + (NBUF + buf) * TILE_BYTES + pc * 1024, v_src[i] + j * v_tile_stride);
     }
+  };
+  X8 qf[DS];
+  // request a block's first two K/V tiles and its Q fragments (nothing is waited for here)
+  auto prefetch = [&](const Blk& k) {
+    if (k.nt > 0) dma_issue(k, 0, 0);
+    if (PD > 1 && k.nt > 1) dma_issue(k, 1, 1);
+    const int row = k.mb * BM + wave * 32 + qi;
+    const int qoff = row * (int)p.qs_n * 2 + hi * 16;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(k.q_rs, qoff + s * 32, 0, 0);
+      qf[s] = __builtin_bit_cast(X8, t);
+    }
+  };
+
+  int item = blockIdx.x, pass = 0, nt_total = 0;
+  bool first = true;
+  if (item >= nitems) return;
+  Blk cur;
+  decode(item, pass, cur);
+  prefetch(cur);
+
+  while (true) {
+    const int nt = cur.nt;
+    nt_total += nt;
+    const int wave_row0 = cur.mb * BM + wave * 32;
+    const int my_row = wave_row0 + qi;
+
     f32x16 oacc[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d)
@@ -163,18 +175,19 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
     float m_run = -1e30f;
     float l_run = 0.f;
 
+    // tiles 0/1 and Q have been requested (prologue, or beside the previous block's epilogue)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));
     asm volatile("s_barrier" ::: "memory");
-    if (p.trace && pass == 0) t_pro = __builtin_amdgcn_s_memtime();
+    if (p.trace && first) t_pro = __builtin_amdgcn_s_memtime();
 
     const int wave_last_tile = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (nt - 1);
 
     auto tile_body = [&](int j, int buf) {
       // tile j+2 goes into the buffer tile j-1 just vacated
-      const bool more = (j + 2 < nt);
-      if (more) dma_issue(j + 2, (buf + 2) % NBUF);
+      const bool more = (j + PD < nt) && !(AB & AB_NOSTAGE);
+      if (more) dma_issue(cur, j + PD, (buf + PD) % NBUF);
 
       if (j <= wave_last_tile) {
         const char* kb = kl + buf * TILE_BYTES;
@@ -192,12 +205,18 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
               const int off = k_rd_base + t * 32 * (D * 2) + (((2 * s + hi) ^ k_rd_swz) << 4);
-              kf[s][t] = __builtin_bit_cast(X8, lds_read_b128(kb, off));
+              if (AB & AB_NOKREAD) kf[s][t] = qf[(s + t) % DS];
+              else kf[s][t] = __builtin_bit_cast(X8, lds_read_b128(kb, off));
             }
+          if (VF & VF_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int s = 0; s < DS; ++s)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) sacc[t] = E::mfma(kf[s][t], qf[s], sacc[t]);
+            for (int t = 0; t < 2; ++t) {
+              if (AB & AB_NOQK) asm volatile("" ::"v"(kf[s][t]));
+              else sacc[t] = E::mfma(kf[s][t], qf[s], sacc[t]);
+            }
+          if (VF & VF_PRIO) __builtin_amdgcn_s_setprio(0);
         }
 
         s16x8 vfr[DT][4];
@@ -206,9 +225,13 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
 #pragma unroll
           for (int d = 0; d < DT; ++d) {
             const char* a = vb + v_rd_base + (s * 2 * DT << 9) + (d << 9);
-            s16x4 lo = lds_read_tr16_b64(a);
-            s16x4 hh = lds_read_tr16_b64(a + 256);
-            vfr[d][s] = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+            if (AB & AB_NOVREAD) {
+              vfr[d][s] = __builtin_bit_cast(s16x8, qf[(d + s) % DS]);
+            } else {
+              s16x4 lo = lds_read_tr16_b64(a);
+              s16x4 hh = lds_read_tr16_b64(a + 256);
+              vfr[d][s] = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
           }
 
         const int key0 = j * BN;
@@ -228,12 +251,14 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
         }
 
         float mloc = sacc[0][0];
+        if (!(AB & AB_NOSM)) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[t][r]);
-        mloc = pair_max(mloc);
-        const float m_new = fmaxf(m_run, mloc);
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[t][r]);
+          mloc = pair_max(mloc);
+        }
+        const float m_new = (AB & AB_NOSM) ? m_run : fmaxf(m_run, mloc);
         const bool changed = (m_new != m_run);
         if (__any(changed)) {
           const float alpha = fast_exp2((m_run - m_new) * sc);
@@ -251,49 +276,81 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float e = fast_exp2(fmaf(sacc[t][r], sc, -msc));
-            lsum[r & 3] += e;
+            float e;
+            if (AB & AB_NOSM) e = sacc[t][r];
+            else e = fast_exp2(fmaf(sacc[t][r], sc, -msc));
+            if (!(AB & AB_NOSM)) lsum[r & 3] += e;
             pk[t * 2 + (r >> 3)][r & 7] = (T)e;
           }
         l_run += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
 
+        if (VF & VF_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int d = 0; d < DT; ++d)
-            oacc[d] = E::mfma(__builtin_bit_cast(X8, vfr[d][s]), pk[s], oacc[d]);
+          for (int d = 0; d < DT; ++d) {
+            if (AB & AB_NOPV) asm volatile("" ::"v"(vfr[d][s]), "v"(pk[s]));
+            else oacc[d] = E::mfma(__builtin_bit_cast(X8, vfr[d][s]), pk[s], oacc[d]);
+          }
+        if (VF & VF_PRIO) __builtin_amdgcn_s_setprio(0);
       }
 
       // tile j+1 must have landed (this wave's pieces; the barrier covers everyone else's), and
       // every wave must be done reading tile j before tile j+3 overwrites it.  Counted wait: the
       // 2*PPW pieces of tile j+2 issued above may stay in flight.
-      if (more) {
+      if (more && PD > 1) {
         if (PPW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if (PPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (AB & 256) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // AB_NOBARRIER (timing only)
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
-    for (int j = 0; j < nt; j += 3) {
-      tile_body(j, 0);
-      if (j + 1 < nt) tile_body(j + 1, 1);
-      if (j + 2 < nt) tile_body(j + 2, 2);
+    if (NBUF == 3) {
+      for (int j = 0; j < nt; j += 3) {
+        tile_body(j, 0);
+        if (j + 1 < nt) tile_body(j + 1, 1);
+        if (j + 2 < nt) tile_body(j + 2, 2);
+      }
+    } else {
+      for (int j = 0; j < nt; j += 2) {
+        tile_body(j, 0);
+        if (j + 1 < nt) tile_body(j + 1, 1);
+      }
     }
-    if (p.trace && pass == 0) t_loop = __builtin_amdgcn_s_memtime();
+    if (p.trace && first) t_loop = __builtin_amdgcn_s_memtime();
+    first = false;
 
-    // ---- epilogue ---------------------------------------------------------------------------
+    // ---- next block of the stream: request its first tiles and Q now, behind them the epilogue ----
+    const int cur_bh = cur.bh;
+    bool have_next;
+    if (PAIR && pass == 0 && (p.nmb - 1 - cur.wi) != cur.wi) {
+      pass = 1;
+      have_next = true;
+    } else {
+      pass = 0;
+      item += gridDim.x;
+      have_next = item < nitems;
+    }
+    if (have_next) {
+      decode(item, pass, cur);
+      prefetch(cur);            // LDS buffers are free: every wave passed the last tile's barrier
+    }
+
+    // ---- epilogue of the block just finished ------------------------------------------------------
+    const int ob = cur_bh / p.H, oh = cur_bh - ob * p.H;
     const float l_tot = pair_sum(l_run);
     const bool empty = !(l_tot > 0.f);
     const float inv = empty ? 1.f : 1.f / l_tot;
     if (p.lse != nullptr && hi == 0 && my_row < p.Nq) {
       const float lse = empty ? INFINITY : (m_run * p.scale + __builtin_amdgcn_logf(l_tot) * 0.6931471805599453f);
-      p.lse[(long long)bh * p.Nq + my_row] = lse;
+      p.lse[(long long)cur_bh * p.Nq + my_row] = lse;
     }
     if (F32OUT) {
-      float* obase = reinterpret_cast<float*>(p.o) + b * p.os_b + h * p.os_h;
+      float* obase = reinterpret_cast<float*>(p.o) + ob * p.os_b + oh * p.os_h;
       auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
       const int ooff = my_row * (int)p.os_n * 4 + hi * 16;
 #pragma unroll
@@ -304,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, ooff + (d * 32 + g * 8) * 4, 0, 0);
         }
     } else {
-      T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
+      T* obase = reinterpret_cast<T*>(p.o) + ob * p.os_b + oh * p.os_h;
       auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
       const int ooff = my_row * (int)p.os_n * 2 + hi * 8;
       typedef __attribute__((ext_vector_type(4))) T t4;
@@ -316,6 +373,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, ooff + (d * 32 + g * 8) * 2, 0, 0);
         }
     }
+    if (!have_next) break;
   }
 
   if (p.trace) {
@@ -327,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
       t[4] = (unsigned long long)nt_total;
       t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);
       t[6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);
-      t[7] = ((unsigned long long)bh << 32) | (unsigned)wi;
+      t[7] = (unsigned long long)blockIdx.x;
     }
   }
 }

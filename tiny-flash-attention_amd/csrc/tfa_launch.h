@@ -4,6 +4,7 @@
 #include "tfa_fwd_kernel.h"
 #include "tfa_fwd_kernel_pp.h"
 #include "tfa_fwd_kernel_dma.h"
+#include "tfa_fwd_kernel_swp.h"
 
 namespace tfa {
 
@@ -29,10 +30,18 @@ static const Variant kVariants[] = {
     {"pp8-pair-vpre4 (ping-pong; all V fragments read ahead in the 1st half)", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT), 1},
     {"dma8-pair (LDS-DMA staging, 3 tile buffers, counted vmcnt; 8 waves)", 8, VF_DMA | VF_PAIR, 1},
     {"dma4-pair (LDS-DMA staging, 3 tile buffers; 4 waves, 1 workgroup/CU by LDS)", 4, VF_DMA | VF_PAIR, 1},
+    {"dma8-pair-setprio", 8, VF_DMA | VF_PAIR | VF_PRIO, 1},
+    {"swp8-pair (LDS-DMA + software-pipelined loop: softmax(j) beside QK^T(j+1), PV(j) beside rowmax(j+1))", 8, VF_DMA | VF_SWP | VF_PAIR, 1},
+    {"dma8-pair-persistent (256 workgroups walk the work items; next block prefetched behind the epilogue)", 8, VF_DMA | VF_PAIR | VF_PERSIST, 1},
+    {"dma4-pair-persistent (128-row blocks, 256 persistent workgroups)", 4, VF_DMA | VF_PAIR | VF_PERSIST, 1},
+    {"dma4-pair-2buf (128-row blocks, two LDS buffers: two workgroups per CU)", 4, VF_DMA | VF_PAIR | VF_2BUF, 1},
+    {"dma4-pair-2buf-persistent", 4, VF_DMA | VF_PAIR | VF_2BUF | VF_PERSIST, 1},
+    {"dma8-pair-2buf (two LDS buffers, prefetch distance one tile)", 8, VF_DMA | VF_PAIR | VF_2BUF, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 11;     // dma8-pair
-constexpr int kSmallGridVariant = 12;   // dma4-pair (128-row query blocks)
+constexpr int kDefaultVariant = 19;     // dma8-pair-2buf
+constexpr int kCausalVariant = 17;      // dma4-pair-2buf (128-row query blocks, two workgroups per CU)
+constexpr int kSmallGridVariant = 17;
 
 struct LaunchGeom {
   int grid, block, lds;
