@@ -165,6 +165,13 @@ def main():
     if rank == 0:
         grid, block, ldsb = C.c_int(), C.c_int(), C.c_int()
         L.tfa_fwd_plan(pref, C.byref(grid), C.byref(block), C.byref(ldsb))
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC profile of this same command (profiles/)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            if args.variant < 0 and args.config in tj:
+                traffic = tj[args.config]["bytes"]
+        except Exception:
+            traffic = None
         line = {
             "metric": "fwd TFLOPS + achieved %MFMA-roofline, (B=4,H=32,N=4096,D=128) bf16",
             "value": value,
@@ -195,7 +202,7 @@ def main():
                 "peak": PEAK_TFLOPS_BF16,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_TFLOPS_BF16,
-                "traffic": None,
+                "traffic": traffic,
                 "launch_ms": ev_ms,
                 "algorithmic_hbm_GBs": by.value / (ev_ms * 1e-3) / 1e9,
                 "hbm_frac": by.value / (ev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,

@@ -300,3 +300,37 @@ def test_strided_bnhd_matches_bhnd(tfa, oracle, dev):
     qt, kt, vt = (t.transpose(1, 2).contiguous() for t in (qd, kd, vd))     # (B,N,H,D) storage
     o_bnhd, l_bnhd = ops.flash_attn_fwd(qt, kt, vt, True, 0.09, layout="bnhd")
     assert torch.equal(o_bnhd.transpose(1, 2), o_bhnd) and torch.equal(l_bnhd, l_bhnd)
+
+
+def test_dropin_extension_module_attention_cutlass(tfa, oracle, dev):
+    """`from attention_cutlass import flash_attention_v2_cutlass` — the reference's own import line
+    (flash_attention_cutlass/test.py:3) — resolves to the C++ binding over the C ABI and returns the
+    same bits as the Python mirror."""
+    import importlib
+    import os
+    import sys
+
+    libdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tiny-flash-attention_amd", "lib")
+    sys.path.insert(0, libdir)
+    try:
+        mod = importlib.import_module("attention_cutlass")
+    finally:
+        sys.path.remove(libdir)
+    q, k, v = oracle.make_inputs(2, 8, 1024, 64, torch.float16, seed=6)     # reference test shape family (test.py:49)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    sm_scale = 1.0 / math.sqrt(1024)                                          # the reference's quirk (test.py:63)
+    out, lse = mod.flash_attention_v2_cutlass(qd, kd, vd, True, sm_scale)
+    out2, lse2 = tfa.flash_attention_v2_cutlass(qd, kd, vd, True, sm_scale)
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
+    # the reference's own check (test.py:19-27, 87): PyTorch naive attention, atol 1e-2
+    p = torch.matmul(qd, kd.transpose(2, 3)) * sm_scale
+    M = torch.tril(torch.ones((1024, 1024), device=dev))
+    p[:, :, M == 0] = float("-inf")
+    base = torch.matmul(torch.softmax(p.float(), dim=-1).half(), vd)
+    assert torch.allclose(base, out, rtol=0, atol=1e-2)
+    with pytest.raises(RuntimeError, match="q must be contiguous"):
+        mod.flash_attention_v2_cutlass(qd.transpose(1, 2), kd, vd, True, sm_scale)
+    with pytest.raises(RuntimeError, match="q must be a CUDA tensor"):
+        mod.flash_attention_v2_cutlass(q, k, v, True, sm_scale)
+    with pytest.raises(TypeError):
+        mod.flash_attention_v2_cutlass(qd, kd, vd)          # positional-only, all five required... (no py::arg)
