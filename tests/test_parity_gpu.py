@@ -101,7 +101,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", list(range(20)))
+@pytest.mark.parametrize("variant", list(range(21)))
 @pytest.mark.parametrize("dtype,B,H,N,D,causal", SHAPES)
 def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
     from tiny_flash_attention_amd import _lib
@@ -207,7 +207,7 @@ def test_inputs_not_modified_and_deterministic(tfa, oracle, dev):
 # ---------------------------------------------------------------------------------------------
 # data-dependent branch: the exact "max unchanged -> skip the O rescale" path and late max jumps
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [1, 2, 5, 10, 11, 14, 15, 17, 18, 19])
+@pytest.mark.parametrize("variant", [1, 2, 5, 10, 11, 14, 15, 17, 18, 19, 20])
 def test_late_max_jump_spike(tfa, oracle, dev, variant):
     from tiny_flash_attention_amd import _lib, ops
 

@@ -136,6 +136,7 @@ constexpr int VF_TRREAD = 1;     // V fragments by ds_read_b64_tr_b16 (else 16-b
 constexpr int VF_NOSKIP = 2;     // always rescale O (no exact alpha==1 skip)
 constexpr int VF_PAIR = 4;       // causal: one workgroup walks query blocks (nmb-1-i) and (i): equal work per workgroup
 constexpr int VF_KPRE = 8;       // read all K fragments of a tile into registers before the QK^T MFMAs
+constexpr int VF_W64 = 8192;     // 64 rows per wave, AGPR-pinned O (tfa_fwd_kernel_w64.h)
 constexpr int VF_SWP = 128;      // software-pipelined DMA kernel (tfa_fwd_kernel_swp.h)
 constexpr int VF_DMA = 64;       // LDS-DMA staging kernel (tfa_fwd_kernel_dma.h)
 constexpr int VF_PP = 32;        // ping-pong schedule (tfa_fwd_kernel_pp.h)

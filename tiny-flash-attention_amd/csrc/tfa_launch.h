@@ -5,6 +5,7 @@
 #include "tfa_fwd_kernel_pp.h"
 #include "tfa_fwd_kernel_dma.h"
 #include "tfa_fwd_kernel_swp.h"
+#include "tfa_fwd_kernel_w64.h"
 
 namespace tfa {
 
@@ -37,6 +38,7 @@ static const Variant kVariants[] = {
     {"dma4-pair-2buf (128-row blocks, two LDS buffers: two workgroups per CU)", 4, VF_DMA | VF_PAIR | VF_2BUF, 1},
     {"dma4-pair-2buf-persistent", 4, VF_DMA | VF_PAIR | VF_2BUF | VF_PERSIST, 1},
     {"dma8-pair-2buf (two LDS buffers, prefetch distance one tile)", 8, VF_DMA | VF_PAIR | VF_2BUF, 1},
+    {"w64-pair (4 waves x 64 rows, one wave per SIMD, O accumulators pinned in AGPRs by inline-asm MFMA)", 4, VF_DMA | VF_W64 | VF_PAIR, 2},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 19;     // dma8-pair-2buf
