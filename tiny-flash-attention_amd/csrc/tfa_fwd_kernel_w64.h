@@ -48,7 +48,8 @@ template <> struct MfmaAsm<_Float16> {
   }
 };
 
-template <typename T, int D, bool CAUSAL, bool F32OUT, int VF>
+// AB: timing-only ablation bits (1: no exponentials, 2: no barrier, 4: no DMA, 8: no max/mask) — results are wrong when set
+template <typename T, int D, bool CAUSAL, bool F32OUT, int VF, int AB = 0>
 __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KArgs p) {
   using E = Elem<T>;
   using X8 = typename E::x8;
@@ -263,10 +264,14 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KArgs p) {
       // The empty asm statements pin each piece between the MFMAs around it.
       auto exp2_pair = [&](const f32x16 (&sc2)[2], float msc, int idx, float (&lsum)[4], X8 (&pkk)[4]) {
         const int e = idx * 2, t = e >> 4, r = e & 15;      // r is even: both elements land in one 32-bit P word
-        float e0 = fast_exp2(fmaf(sc2[t][r], sc, -msc));
-        float e1 = fast_exp2(fmaf(sc2[t][r + 1], sc, -msc));
-        lsum[r & 3] += e0;
-        lsum[(r + 1) & 3] += e1;
+        float e0, e1;
+        if (AB & 1) { e0 = sc2[t][r]; e1 = sc2[t][r + 1]; }
+        else {
+          e0 = fast_exp2(fmaf(sc2[t][r], sc, -msc));
+          e1 = fast_exp2(fmaf(sc2[t][r + 1], sc, -msc));
+          lsum[r & 3] += e0;
+          lsum[(r + 1) & 3] += e1;
+        }
         pkk[t * 2 + (r >> 3)][r & 7] = (T)e0;
         pkk[t * 2 + (r >> 3)][(r + 1) & 7] = (T)e1;
         asm volatile("" : "+v"(lsum[r & 3]), "+v"(lsum[(r + 1) & 3]), "+v"(pkk[t * 2 + (r >> 3)]));
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KArgs p) {
           }
 #pragma unroll
         for (int t = 0; t < 2; ++t) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sacc[0][t]));
-        rescale(0, mask_max(0, sacc[0]));
+        if (!(AB & 8)) rescale(0, mask_max(0, sacc[0]));
         const float msc0 = m_run[0] * sc;
 
         // ---- stage B: S1 = K Q1^T, exponentials of row block 0 behind every MFMA ------------------
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KArgs p) {
         l_run[0] += (lsum0[0] + lsum0[1]) + (lsum0[2] + lsum0[3]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sacc[1][t]));
-        rescale(1, mask_max(1, sacc[1]));
+        if (!(AB & 8)) rescale(1, mask_max(1, sacc[1]));
         const float msc1 = m_run[1] * sc;
 
         // ---- stage C: O0 += P0 V, exponentials of row block 1 behind every MFMA --------------------
@@ -335,8 +340,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KArgs p) {
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (j + 3 < nt) dma_issue(j + 3, buf);
+      if (AB & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (j + 3 < nt && !(AB & 4)) dma_issue(j + 3, buf);
       if (j + 1 < nt && j + 1 <= wave_last_tile) read_k((buf + 1) % NBUF);
 
       if (active) {
