@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtfa_hip.so")
+LIB_PATH = os.environ.get("TFA_LIB") or os.path.join(_HERE, "lib", "libtfa_hip.so")   # TFA_LIB: developer override (A/B of builds)
 
 TFA_F16, TFA_BF16, TFA_F32 = 0, 1, 2
 

@@ -38,6 +38,7 @@ static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsi
 
 constexpr int VF_PERSIST = 2048;   // launch one workgroup per CU and walk the work items (else one item per workgroup)
 constexpr int VF_2BUF = 4096;      // two LDS tile buffers (64 KiB at D=128): two 4-wave workgroups fit one CU
+constexpr int VF_LDSEPI = 16384;   // epilogue: transpose O through LDS and store whole rows (16-byte coalesced stores)
 constexpr int VF_PRIO = 1024;   // s_setprio(1) around the MFMA clusters (experiment, tools/ab.py)
 
 // The kernel walks a STREAM of query blocks: workgroup g takes work items g, g+G, g+2G, ... (G =
@@ -324,8 +325,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
     if (p.trace && first) t_loop = __builtin_amdgcn_s_memtime();
     first = false;
 
-    // ---- next block of the stream: request its first tiles and Q now, behind them the epilogue ----
+    // ---- next block of the stream ----------------------------------------------------------------
     const int cur_bh = cur.bh;
+    constexpr bool LDS_EPI = !F32OUT && (VF & VF_LDSEPI);   // 16-bit O goes out through LDS as whole rows
     bool have_next;
     if (PAIR && pass == 0 && (p.nmb - 1 - cur.wi) != cur.wi) {
       pass = 1;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
       item += gridDim.x;
       have_next = item < nitems;
     }
-    if (have_next) {
+    if (have_next && !LDS_EPI) {
       decode(item, pass, cur);
       prefetch(cur);            // LDS buffers are free: every wave passed the last tile's barrier
     }
@@ -360,6 +362,40 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
           f32x4 v4 = {oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv};
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, ooff + (d * 32 + g * 8) * 4, 0, 0);
         }
+    } else if (LDS_EPI) {
+      // Each lane holds 4-element pieces of ONE row scattered over 16 registers groups: stored directly that is
+      // 16 eight-byte stores per lane to 32 different rows per instruction.  Instead the wave transposes its
+      // 32 x D tile through its own slice of the (now idle) K buffers — 16-byte chunk index XOR row, as for K —
+      // and writes whole rows: 1 KiB contiguous per store instruction.
+      T* obase = reinterpret_cast<T*>(p.o) + ob * p.os_b + oh * p.os_h;
+      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      typedef __attribute__((ext_vector_type(4))) T t4;
+      char* const ow = smem + wave * (32 * D * 2);
+      constexpr int CH = D / 8;                      // 16-byte chunks per row
+      const int osw = (CH == 16) ? (qi & 15) : (qi & 7);
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          t4 v4 = {(T)(oacc[d][4 * g + 0] * inv), (T)(oacc[d][4 * g + 1] * inv), (T)(oacc[d][4 * g + 2] * inv), (T)(oacc[d][4 * g + 3] * inv)};
+          const int c = d * 4 + g;
+          *reinterpret_cast<u32x2*>(ow + qi * (D * 2) + ((c ^ osw) << 4) + hi * 8) = __builtin_bit_cast(u32x2, v4);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slice: no barrier needed
+      constexpr int RPI = 64 / CH;                   // rows per store instruction (4 at D=128, 8 at D=64)
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int r = i * RPI + lane / CH, cpos = lane % CH;
+        const int c = cpos ^ ((CH == 16) ? (r & 15) : (r & 7));
+        u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
+        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, (wave_row0 + r) * (int)p.os_n * 2 + (c << 4), 0, 0);
+      }
+      if (have_next) {
+        // the next block's DMA will overwrite these slices: every wave must have read its rows back
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        decode(item, pass, cur);
+        prefetch(cur);
+      }
     } else {
       T* obase = reinterpret_cast<T*>(p.o) + ob * p.os_b + oh * p.os_h;
       auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);

@@ -39,6 +39,8 @@ static const Variant kVariants[] = {
     {"dma4-pair-2buf-persistent", 4, VF_DMA | VF_PAIR | VF_2BUF | VF_PERSIST, 1},
     {"dma8-pair-2buf (two LDS buffers, prefetch distance one tile)", 8, VF_DMA | VF_PAIR | VF_2BUF, 1},
     {"w64-pair (4 waves x 64 rows, one wave per SIMD, O accumulators pinned in AGPRs by inline-asm MFMA)", 4, VF_DMA | VF_W64 | VF_PAIR, 2},
+    {"dma4-pair-2buf-ldsepi (O leaves through LDS as whole rows, 16-byte stores)", 4, VF_DMA | VF_PAIR | VF_2BUF | VF_LDSEPI, 1},
+    {"dma8-pair-2buf-ldsepi", 8, VF_DMA | VF_PAIR | VF_2BUF | VF_LDSEPI, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 19;     // dma8-pair-2buf
