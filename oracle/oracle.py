@@ -173,6 +173,60 @@ def tiled_emulation(q, k, v, is_causal, softmax_scale, block_n=64, p_dtype=None,
     return out
 
 
+def tiled_emulation_lazy(q, k, v, is_causal, softmax_scale, block_n=64, group=32, thresh=8.0, p_dtype=None,
+                         return_lse=False):
+    """The same tile loop as ``tiled_emulation`` with the issue-interleaved kernel's max rule
+    (tiny-flash-attention_amd/csrc/tfa_fwd_kernel_il.h): instead of the exact running max of
+    main_torch_only.py:240-257 every row keeps a REFERENCE exponent ``ref`` (log2 domain).  A group of
+    ``group`` consecutive query rows (one wave) re-bases only when some row's tile max exceeds its
+    ``ref`` by more than ``thresh`` (2^8): then every row of the group takes ref = max(ref, tile max) and
+    O, l are multiplied by exp2(old - new).  P = exp2(s*scale*log2e - ref) <= 2^thresh, so nothing can
+    overflow, and the final O = acc / l and LSE = (ref + log2 l) ln2 are unchanged mathematically; only the
+    rounding points of the 16-bit P move.  With thresh=0 and group=1 this is the exact-max rule again."""
+    B, H, Nq, D = q.shape
+    _, Hk, Nk, _ = k.shape
+    dt = q.dtype if p_dtype is None else p_dtype
+    qf = q.detach().cpu().float()
+    kf = k.detach().cpu().float()
+    vf = v.detach().cpu().float()
+    if Hk != H:
+        kf = kf.repeat_interleave(H // Hk, dim=1)
+        vf = vf.repeat_interleave(H // Hk, dim=1)
+    sc2 = torch.tensor(softmax_scale * 1.4426950408889634, dtype=torch.float32)
+    ngrp = (Nq + group - 1) // group
+    pad = ngrp * group - Nq
+    acc = torch.zeros((B, H, Nq, D), dtype=torch.float32)
+    l = torch.zeros((B, H, Nq, 1), dtype=torch.float32)
+    ref = torch.full((B, H, Nq, 1), -1e30, dtype=torch.float32)
+    rows = torch.arange(Nq)[:, None] + (Nk - Nq)
+    for kv_start in range(0, Nk, block_n):
+        k_tile = kf[:, :, kv_start:kv_start + block_n, :]
+        v_tile = vf[:, :, kv_start:kv_start + block_n, :]
+        s = torch.matmul(qf, k_tile.transpose(2, 3))
+        if is_causal:
+            cols = kv_start + torch.arange(k_tile.shape[2])[None, :]
+            s = s.masked_fill(cols > rows, -math.inf)
+        xm = s.max(dim=-1, keepdim=True).values * sc2                       # fp32 product, as the kernel
+        over = xm > ref + thresh
+        og = torch.nn.functional.pad(over, (0, 0, 0, pad)).view(B, H, ngrp, group).any(dim=-1, keepdim=True)
+        trig = og.expand(B, H, ngrp, group).reshape(B, H, ngrp * group, 1)[:, :, :Nq]
+        nref = torch.where(trig, torch.maximum(ref, xm), ref)
+        alpha = torch.exp2(ref - nref)
+        l = l * alpha
+        acc = acc * alpha
+        ref = nref
+        x = (s.double() * sc2.double() - ref.double()).float()              # one rounding, like v_fma_f32
+        pr = torch.exp2(x)
+        l = l + pr.sum(dim=-1, keepdim=True)
+        acc = acc + torch.matmul(pr.to(dt).float(), v_tile)
+    empty = l == 0
+    out = torch.where(empty, torch.zeros_like(acc), acc / torch.where(empty, torch.ones_like(l), l))
+    if return_lse:
+        lse = torch.where(empty, torch.full_like(l, math.inf), (ref + torch.log2(l)) * 0.6931471805599453).squeeze(-1)
+        return out, lse
+    return out
+
+
 def abs_weighted(q, k, v, is_causal, softmax_scale):
     """A[i,d] = sum_j P[i,j] |v[j,d]| — the non-cancelling magnitude of each output element; the
     natural scale for error bounds on O (|O| <= A, with equality when no cancellation)."""

@@ -1,0 +1,539 @@
+// tfa_fwd_kernel_il.h — forward kernel with an ISSUE-INTERLEAVED tile loop (gfx950).
+//
+// Why (tools/probe_issue.hip, tools/probe_overlap.hip, profiles/r01_pmc_default_cfg3.txt):
+//   * one SIMD has ONE VALU issue port; a v_mfma_f32_32x32x16 keeps the matrix pipe busy for 32 cycles but
+//     the port only for ~4-8, so ~5 ordinary VALU instructions (a v_exp_f32 counts as 2) issued by the SAME
+//     wave right behind an MFMA run for free in its shadow;
+//   * a wave that streams MFMAs back to back re-arms the port the moment it frees, so VALU work of the
+//     OTHER wave on that SIMD is starved (head-of-line), and s_setprio does not change that;
+//   * in the burst-structured kernels (QK^T burst, softmax burst, PV burst) the PMC counters show
+//     time ~= MFMA time + VALU time: nothing overlaps.
+// So the loop below is software-pipelined inside each wave and the order is pinned MFMA by MFMA with
+// sched_barrier(0): every MFMA is followed by its share of the softmax VALU work of ANOTHER tile.
+//
+//   iteration j:   part 1   S(j+1) = K(j+1) Q^T   (2*D/16 MFMAs)  each followed by exp2/sum/pack of ~1.25 elements of tile j
+//                  part 2   O += P(j) V(j)        (4*D/32 MFMAs)  each followed by 1 element of tile j (first 3/4) and
+//                                                                  one v_max3 of the row max of S(j+1)
+//   P(j) slot s (16 keys) is complete before the first PV MFMA that consumes it.  K tiles run one tile
+//   ahead of V tiles in LDS (iteration j reads K(j+1) and V(j)); two K and two V buffers, refilled by
+//   LDS-DMA at the top of the iteration that follows their last read; one workgroup barrier per tile.
+//   The loop is unrolled by two so buffer addresses are immediates and S(j)/S(j+1) swap without copies.
+//   Tiles that need masking (causal diagonal, ragged tail) run the same body with the mask applied
+//   between the two parts (template flag, real branch: never if-converted into the steady state).
+#pragma once
+#include <type_traits>
+#include "tfa_fwd_kernel_dma.h"
+
+namespace tfa {
+
+constexpr int VF_IL = 32768;        // issue-interleaved kernel (this file)
+constexpr int VF_IL_DMASPREAD = 65536;   // issue the LDS-DMA pieces between MFMAs of part 1 instead of at the top
+
+// ---- O accumulators in hand-pinned registers v[192:255] ---------------------------------------------------------
+// The kernel is compiled with amdgpu_num_vgpr(96) (LLVM doubles the request on gfx90a+: 192 unified registers): the register allocator owns v0..v191 and never sees O.  With O as
+// ordinary SSA values (builtin MFMA) the allocator split the 64-register live range around the loop and copied all of O
+// between two register sets every iteration; with "+a" (AGPR) operands it halves the VGPR budget to 128.  Every access
+// to O is therefore inline asm naming the physical registers: d tile i lives in v[192+16i : 207+16i].
+#define TFA_O_CLOB0 "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207"
+#define TFA_O_CLOB1 "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223"
+#define TFA_O_CLOB2 "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239"
+#define TFA_O_CLOB3 "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+#define TFA_O_LIST01 "192,193,194,195,196,197,198,199,200,201,202,203,204,205,206,207,208,209,210,211,212,213,214,215,216,217,218,219,220,221,222,223"
+#define TFA_O_LIST23 "224,225,226,227,228,229,230,231,232,233,234,235,236,237,238,239,240,241,242,243,244,245,246,247,248,249,250,251,252,253,254,255"
+template <typename T> struct MfmaName;
+template <> struct MfmaName<__bf16> { static constexpr bool bf = true; };
+template <> struct MfmaName<_Float16> { static constexpr bool bf = false; };
+
+// O[d tile DI] += A.B.  "s_nop 1": a VALU write of an A/B operand needs 2 wait states before an MFMA reads it and the
+// compiler cannot see that this asm is an MFMA.
+#define TFA_PV_CASE(DI, LO, HI, CLOB)                                                                                  \
+  if constexpr (DI == (LO - 192) / 16) {                                                                               \
+    if constexpr (MfmaName<T>::bf)                                                                                     \
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 v[" #LO ":" #HI "], %0, %1, v[" #LO ":" #HI "]" ::"v"(a), "v"(b) : CLOB); \
+    else                                                                                                               \
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 v[" #LO ":" #HI "], %0, %1, v[" #LO ":" #HI "]" ::"v"(a), "v"(b) : CLOB);  \
+  }
+template <typename T, int DI, typename X8> static __device__ __forceinline__ void o_mfma(X8 a, X8 b) {
+  TFA_PV_CASE(DI, 192, 207, TFA_O_CLOB0)
+  TFA_PV_CASE(DI, 208, 223, TFA_O_CLOB1)
+  TFA_PV_CASE(DI, 224, 239, TFA_O_CLOB2)
+  TFA_PV_CASE(DI, 240, 255, TFA_O_CLOB3)
+}
+template <typename T, typename X8> static __device__ __forceinline__ void o_mfma_d(int d, X8 a, X8 b) {   // d folds to a constant
+  if (d == 0) o_mfma<T, 0>(a, b);
+  else if (d == 1) o_mfma<T, 1>(a, b);
+  else if (d == 2) o_mfma<T, 2>(a, b);
+  else o_mfma<T, 3>(a, b);
+}
+template <int DT> static __device__ __forceinline__ void o_zero() {
+  asm volatile(".irp r," TFA_O_LIST01 "\n\tv_mov_b32 v[\\r], 0\n\t.endr" ::: TFA_O_CLOB0, TFA_O_CLOB1);
+  if constexpr (DT == 4) asm volatile(".irp r," TFA_O_LIST23 "\n\tv_mov_b32 v[\\r], 0\n\t.endr" ::: TFA_O_CLOB2, TFA_O_CLOB3);
+}
+// O *= alpha (per lane); the leading s_nops cover the MFMA-write -> VALU-read distance (cold path)
+template <int DT> static __device__ __forceinline__ void o_scale(float alpha) {
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t.irp r," TFA_O_LIST01 "\n\tv_mul_f32 v[\\r], v[\\r], %0\n\t.endr" ::"v"(alpha) : TFA_O_CLOB0, TFA_O_CLOB1);
+  if constexpr (DT == 4)
+    asm volatile(".irp r," TFA_O_LIST23 "\n\tv_mul_f32 v[\\r], v[\\r], %0\n\t.endr" ::"v"(alpha) : TFA_O_CLOB2, TFA_O_CLOB3);
+}
+// out[r] = O[d tile DI][r] * inv
+#define TFA_OR(B, K) "v_mul_f32 %" #K ", v[" #B "+" #K "], %16\n\t"
+#define TFA_OREAD_CASE(DI, B)                                                                                          \
+  if constexpr (DI == (B - 192) / 16)                                                                                  \
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" TFA_OR(B, 0) TFA_OR(B, 1) TFA_OR(B, 2) TFA_OR(B, 3) TFA_OR(B, 4) TFA_OR(B, 5) TFA_OR(B, 6)       \
+                 TFA_OR(B, 7) TFA_OR(B, 8) TFA_OR(B, 9) TFA_OR(B, 10) TFA_OR(B, 11) TFA_OR(B, 12) TFA_OR(B, 13) TFA_OR(B, 14) TFA_OR(B, 15) \
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),  \
+                   "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])\
+                 : "v"(inv));
+template <int DI> static __device__ __forceinline__ void o_read(float (&o)[16], float inv) {
+  TFA_OREAD_CASE(DI, 192)
+  TFA_OREAD_CASE(DI, 208)
+  TFA_OREAD_CASE(DI, 224)
+  TFA_OREAD_CASE(DI, 240)
+}
+
+// AB: timing-only ablation bits of the fast path (results are wrong when set; tools/ablate_il.py)
+constexpr int ILAB_NOEXP = 1, ILAB_NODMA = 2, ILAB_NOBARRIER = 4, ILAB_NOMAX = 8, ILAB_NOQK = 16, ILAB_NOPV = 32, ILAB_NOKREAD = 64, ILAB_NOVREAD = 128;
+
+template <typename T, int D, int NW, bool CAUSAL, bool F32OUT, int VF, int AB = 0>
+__global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) void fwd_kernel_il(const KArgs p) {
+  using E = Elem<T>;
+  using X8 = typename E::x8;
+  constexpr int BM = NW * 32;
+  constexpr int BN = 64;
+  constexpr int CPR = D / 8;
+  constexpr int TILE_BYTES = BN * D * 2;
+  constexpr int PIECES = TILE_BYTES / 1024;
+  constexpr int PPW = PIECES / NW;                 // DMA pieces per wave per tensor per tile
+  constexpr int DS = D / 16;
+  constexpr int DT = D / 32;
+  constexpr int N1 = 2 * DS;                       // QK^T MFMAs per tile
+  constexpr int N2 = 4 * DT;                       // PV MFMAs per tile
+  constexpr int NE1 = 21;                          // softmax elements (of 32 per lane) handled in part 1
+  constexpr int PFK = 2, PFV = 2;                  // fragment read-ahead, in MFMAs
+#ifndef TFA_IL_QKSPLIT
+#define TFA_IL_QKSPLIT 0
+#endif
+  // QK^T MFMA i works on key block KT(i) with k-slot KS(i): interleaved (0) or one key block after the other (1)
+  constexpr bool QKSPLIT = TFA_IL_QKSPLIT;
+#define KT(i) (QKSPLIT ? (i) / DS : (i) & 1)
+#define KS(i) (QKSPLIT ? (i) % DS : (i) >> 1)
+  constexpr bool PAIR = CAUSAL && (VF & VF_PAIR);
+  static_assert(PPW >= 1 && PPW * NW == PIECES, "tile does not split into whole DMA pieces per wave");
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* const kl = smem;                           // K buffers 0,1
+  char* const vl = smem + 2 * TILE_BYTES;          // V buffers 0,1
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
+  if (p.trace) t_start = __builtin_amdgcn_s_memtime();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 31;
+  const int hi = lane >> 5;
+
+  int bh, wi;
+  {
+    const int id = blockIdx.x;
+    if ((p.nbh & 7) == 0) {
+      const int x = id & 7, s = id >> 3;
+      bh = x + 8 * (s / p.nwork);
+      wi = s % p.nwork;
+    } else {
+      bh = id / p.nwork;
+      wi = id % p.nwork;
+    }
+  }
+  const int b = bh / p.H;
+  const int h = bh - b * p.H;
+  const int hk = h / (p.H / p.Hk);
+  const int shift = p.Nk - p.Nq;
+
+  const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
+  const T* kbase = reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h;
+  const T* vbase = reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h;
+  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, p.q_bytes, 0x00020000);
+  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
+  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
+
+  int k_src[PPW], v_src[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pc = wave * PPW + i;
+    {
+      const int row = pc * (1024 / (D * 2)) + lane / CPR;
+      const int cpos = lane % CPR;
+      k_src[i] = row * (int)p.ks_n * 2 + ((cpos ^ k_swz<D>(row)) << 4);
+    }
+    {
+      const int o = pc * 1024 + lane * 16;
+      const int sub = o >> 9, R = (o >> 6) & 7, pcs = (o >> 4) & 3;
+      const int dt = sub % DT, sh = sub / DT;
+      const int key = 16 * (sh >> 1) + 4 * (sh & 1) + 8 * (R >> 2) + (R & 3);
+      v_src[i] = key * (int)p.vs_n * 2 + ((dt * 4 + pcs) << 4);
+    }
+  }
+  const int k_tile_stride = BN * (int)p.ks_n * 2;
+  const int v_tile_stride = BN * (int)p.vs_n * 2;
+
+  auto dma_k1 = [&](int t, int buf, int i) {
+    lds_dma16(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
+  };
+  auto dma_v1 = [&](int t, int buf, int i) {
+    lds_dma16(v_rs, lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i] + t * v_tile_stride);
+  };
+  auto dma_k = [&](int t, int buf) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) dma_k1(t, buf, i);
+  };
+  auto dma_v = [&](int t, int buf) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) dma_v1(t, buf, i);
+  };
+
+  // K fragment of k-slot sl: 16-byte chunk (2*sl + hi) ^ swz of row qi.  2*sl and hi do not share bits, so the LDS
+  // address is (row base + ((hi ^ swz) << 4)) ^ (sl << 5): one register and one v_xor per read pair (smem is 1 KiB aligned).
+  unsigned k_rd_addr = lds_base + qi * (D * 2) + ((hi ^ k_swz<D>(qi)) << 4);
+  asm volatile("" : "+v"(k_rd_addr));
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
+  const float sc = p.scale_log2;
+  int nt_total = 0;
+
+  const int npass = PAIR ? ((p.nmb - 1 - wi) != wi ? 2 : 1) : 1;
+#pragma nounroll
+  for (int pass = 0; pass < npass; ++pass) {
+    int mb;
+    if (PAIR) mb = pass == 0 ? (p.nmb - 1 - wi) : wi;
+    else mb = CAUSAL ? (p.nmb - 1 - wi) : wi;
+    const int q0 = mb * BM;
+    int kv_end = p.Nk;
+    if (CAUSAL) {
+      const int lim = q0 + BM + shift;
+      kv_end = lim < kv_end ? lim : kv_end;
+    }
+    const int nt = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+    nt_total += nt;
+
+    const int wave_row0 = q0 + wave * 32;
+    const int my_row = wave_row0 + qi;
+    const int wave_last_tile = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (nt - 1);
+
+    X8 qf[DS];
+    float l_run = 0.f;
+
+    auto k_frag = [&](int kbuf, int i) -> X8 {   // fragment of QK^T MFMA i: key block i/DS, k-slot i%DS
+      typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
+      const unsigned a = (k_rd_addr ^ (KS(i) << 5)) + kbuf * TILE_BYTES + KT(i) * 32 * (D * 2);
+      return __builtin_bit_cast(X8, *reinterpret_cast<lds_u32x4*>(a));
+    };
+    auto k_frag_rt = [&](unsigned kb_bytes, int i) -> X8 {   // same, K buffer chosen at run time
+      typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
+      const unsigned a = (k_rd_addr ^ (KS(i) << 5)) + kb_bytes + KT(i) * 32 * (D * 2);
+      return __builtin_bit_cast(X8, *reinterpret_cast<lds_u32x4*>(a));
+    };
+    auto v_frag = [&](const char* vb, int i) -> X8 {   // fragment of PV MFMA i: key slot i/DT, d tile i%DT
+      const char* a = vb + v_rd_base + ((i / DT) * 2 * DT << 9) + ((i % DT) << 9);
+      s16x4 lo = lds_read_tr16_b64(a);
+      s16x4 hh = lds_read_tr16_b64(a + 256);
+      return __builtin_bit_cast(X8, __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto needs_mask = [&](int t) -> bool {
+      const int key0 = t * BN;
+      bool nm = (key0 + BN > p.Nk);
+      if (CAUSAL) nm = nm || (key0 + BN - 1 > wave_row0 + shift);
+      return nm;
+    };
+    auto apply_mask = [&](int t, f32x16 (&s)[2]) {
+      int lim = p.Nk - 1;
+      if (CAUSAL) { const int c = my_row + shift; lim = c < lim ? c : lim; }
+      lim -= t * BN + 4 * hi;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ko = 32 * tt + (r & 3) + 8 * (r >> 2);
+          if (ko > lim) s[tt][r] = -INFINITY;
+        }
+    };
+    // Reference exponent of the row ("mref", log2 domain) instead of the exact running max: P = exp2(s*sc - mref)
+    // where mref is the row's scaled running max as of the last re-base.  A wave re-bases (every row takes its current
+    // running max, O and l are multiplied by exp2(old - new)) only when some row max has outgrown its mref by more
+    // than 2^8, so P <= 2^8: nothing can overflow in the fp32 sums or the 16-bit P, and O / l and the LSE are
+    // unchanged mathematically.  That takes the O rescale (64 VALU per tile on ~60% of the tiles at N=4096 with the
+    // exact-max rule, since SOME row of a wave nearly always sees a new max) out of the steady state; it lives in
+    // the slow path below.  oracle/oracle.py:tiled_emulation_lazy restates this rule for the parity tests.
+    float mref = -1e30f;
+    auto trigger = [&](float mloc) -> bool { return __any(mloc * sc > mref + 8.f); };
+    auto rescale_if_needed = [&](float mloc) {
+      const float x = mloc * sc;
+      if (__any(x > mref + 8.f)) {
+        const float nref = fmaxf(mref, x);
+        const float alpha = fast_exp2(mref - nref);
+        l_run *= alpha;
+        o_scale<DT>(alpha);
+        mref = nref;
+      }
+    };
+
+    // one softmax element of the current tile: e in [0,32): P slot e>>3 (16 keys), position e&7.  The empty asm
+    // statements pin each result inside the MFMA slot it was written in (IR passes otherwise re-associate the row
+    // sum into packed adds and sink the row max to the end of the block, keeping all 32 exponentials live).
+    typedef __attribute__((ext_vector_type(2))) T t2;
+    auto soft_elem = [&](int e, const f32x16 (&s)[2], float msc, float (&lsum)[4], unsigned (&pw)[16], float& ev_hold) {
+      const int slot = e >> 3, t = slot >> 1, r = (slot & 1) * 8 + (e & 7);
+      const float ev = fast_exp2(fmaf(s[t][r], sc, -msc));
+      lsum[e & 3] += ev;
+      asm volatile("" : "+v"(lsum[e & 3]));
+      if (e & 1) {
+        const t2 w = {(T)ev_hold, (T)ev};
+        pw[e >> 1] = __builtin_bit_cast(unsigned, w);
+        asm volatile("" : "+v"(pw[e >> 1]));
+      } else {
+        ev_hold = ev;
+      }
+    };
+    auto p_frag = [&](const unsigned (&pw)[16], int slot) -> X8 {
+      const u32x4 w = {pw[4 * slot], pw[4 * slot + 1], pw[4 * slot + 2], pw[4 * slot + 3]};
+      return __builtin_bit_cast(X8, w);
+    };
+
+    // ---- prologue: K(0), V(0), K(1) by DMA, Q fragments, S(0) and its row max -------------------------
+    if (nt > 0) dma_k(0, 0);
+    if (nt > 0) dma_v(0, 0);
+    if (nt > 1) dma_k(1, 1);
+    {
+      const int qoff = my_row * (int)p.qs_n * 2 + hi * 16;
+#pragma unroll
+      for (int s = 0; s < DS; ++s) {
+        u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, qoff + s * 32, 0, 0);
+        qf[s] = __builtin_bit_cast(X8, t);
+      }
+    }
+    o_zero<DT>();
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));
+    asm volatile("s_barrier" ::: "memory");
+    if (p.trace && pass == 0) t_pro = __builtin_amdgcn_s_memtime();
+
+    // tiles this wave computes: 0 .. nact-1 (causal: the waves of a block stop at different tiles)
+    const int nact = (wave_last_tile + 1 < nt) ? (wave_last_tile + 1) : nt;
+    // first tile of this wave that needs masking (causal diagonal or ragged tail); nact if none
+    int fm = nact;
+    {
+      const int ragged = (p.Nk % BN) ? (p.Nk / BN) : nact;
+      fm = ragged < fm ? ragged : fm;
+      if (CAUSAL) {
+        const int c = wave_row0 + shift + 1;               // keys 0..c-1 are visible to every row of the wave
+        const int full = c > 0 ? c / BN : 0;               // tiles 0..full-1 need no mask
+        fm = full < fm ? full : fm;
+      }
+    }
+
+    f32x16 sA[2], sB[2];
+    float mA = -INFINITY, mB = -INFINITY;
+    auto qk_burst = [&](int kbuf, int t, f32x16 (&s)[2], float& mout) {   // S(t) = K(t) Q^T from K buffer kbuf, masked, row max
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[tt][r] = 0.f;
+      const unsigned kb = kbuf * TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < N1; ++i) s[KT(i)] = E::mfma(k_frag_rt(kb, i), qf[KS(i)], s[KT(i)]);
+      if (needs_mask(t)) apply_mask(t, s);
+      float mx = s[0][0];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tt][r]);
+      mout = pair_max(mx);
+    };
+    if (nact > 0) qk_burst(0, 0, sA, mA);
+    // K buffer 0 is refilled with K(2) at the top of iteration 0: every wave must be done with K(0)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    auto iter_end = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---- fast path: tile j (S in scur) -> O; S(j+1) and its row max -> snext, mnext.  One basic block. ---------
+    // PAR = j & 1: K(j+1) is in K buffer PAR^1, V(j) in V buffer PAR; K(j+2) -> K buffer PAR, V(j+1) -> V buffer PAR^1.
+    auto fused = [&](auto par_c, int j, f32x16 (&scur)[2], f32x16 (&snext)[2], float& mnext) {
+      constexpr int PAR = decltype(par_c)::value;
+      constexpr bool SPREAD = (VF & VF_IL_DMASPREAD) != 0;
+      const bool issue_k = (j + 2 < nt);
+      if (!SPREAD && !(AB & ILAB_NODMA)) {
+        if (issue_k) dma_k(j + 2, PAR);
+        dma_v(j + 1, PAR ^ 1);
+      }
+      const float msc = mref;
+      constexpr int KB = PAR ^ 1;
+      const char* vbp = vl + PAR * TILE_BYTES;
+      unsigned pw[16];
+      float ev_hold = 0.f;
+      float lsum[4] = {0.f, 0.f, 0.f, 0.f};
+      X8 kf[N1], vf[N2];
+#pragma unroll
+      for (int i = 0; i < PFK; ++i) kf[i] = k_frag(KB, i);
+      __builtin_amdgcn_sched_barrier(0);
+      // part 1
+#pragma unroll
+      for (int i = 0; i < N1; ++i) {
+        if (i + PFK < N1) kf[i + PFK] = ((AB & ILAB_NOKREAD) && i + PFK >= PFK) ? kf[(i + PFK) % PFK] : k_frag(KB, i + PFK);
+        else vf[i + PFK - N1] = v_frag(vbp, i + PFK - N1);
+        if (AB & ILAB_NOQK) {
+          if (i < 2) asm volatile("" : "+v"(snext[i]));
+        } else if (KS(i) == 0) {                           // first k-slot of a key block: C = 0 (inline constant)
+          f32x16 z;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z[r] = 0.f;
+          snext[KT(i)] = E::mfma(kf[i], qf[KS(i)], z);
+        } else {
+          snext[KT(i)] = E::mfma(kf[i], qf[KS(i)], snext[KT(i)]);
+        }
+        if (SPREAD && !(AB & ILAB_NODMA)) {         // 2*PPW DMA pieces spread over the first MFMAs, one per MFMA
+          if (i < PPW) dma_v1(j + 1, PAR ^ 1, i);
+          else if (i < 2 * PPW) { if (issue_k) dma_k1(j + 2, PAR, i - PPW); }
+        }
+#pragma unroll
+        for (int e = 0; e < NE1; ++e)
+          if (e * N1 / NE1 == i) {
+            if (AB & ILAB_NOEXP) { if (e & 1) pw[e >> 1] = __builtin_bit_cast(unsigned, scur[0][e >> 1]); }
+            else soft_elem(e, scur, msc, lsum, pw, ev_hold);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // part 2
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < N2; ++i) {
+        if (i + PFV < N2) vf[i + PFV] = (AB & ILAB_NOVREAD) ? vf[(i + PFV) % PFV] : v_frag(vbp, i + PFV);
+        if (!(AB & ILAB_NOPV)) o_mfma_d<T>(i % DT, vf[i], p_frag(pw, i / DT));
+        else asm volatile("" ::"v"(vf[i]), "v"(pw[(i / DT) * 4]), "v"(pw[(i / DT) * 4 + 1]), "v"(pw[(i / DT) * 4 + 2]), "v"(pw[(i / DT) * 4 + 3]));
+#pragma unroll
+        for (int e = NE1; e < 32; ++e)
+          if ((e - NE1) * (3 * DT) / (32 - NE1) == i) {
+            if (AB & ILAB_NOEXP) { if (e & 1) pw[e >> 1] = __builtin_bit_cast(unsigned, scur[1][e >> 1]); }
+            else soft_elem(e, scur, msc, lsum, pw, ev_hold);
+          }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)               // 16 pairs of S(j+1) values -> one v_max3 each
+          if (q * N2 / 16 == i && !(AB & ILAB_NOMAX)) {
+            mx = fmaxf(fmaxf(mx, snext[q >> 3][2 * (q & 7)]), snext[q >> 3][2 * (q & 7) + 1]);
+            asm volatile("" : "+v"(mx));
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      l_run += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+      mnext = (AB & ILAB_NOMAX) ? snext[0][0] * 1e-30f : pair_max(mx);
+      if (AB & ILAB_NOBARRIER) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else iter_end();
+    };
+    // ---- slow path: any tile (first, masked, last, rescale needed); S(j) in sA, runtime buffer parity ----------
+    auto slow = [&](int j) {
+      const int par = j & 1;
+      if (j + 2 < nt) dma_k(j + 2, par);
+      if (j + 1 < nt) dma_v(j + 1, par ^ 1);
+      rescale_if_needed(mA);
+      const float msc = mref;
+      const char* vbp = vl + par * TILE_BYTES;
+      unsigned pw[16];
+      float ev_hold = 0.f;
+      float lsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 32; ++e) soft_elem(e, sA, msc, lsum, pw, ev_hold);
+      l_run += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+#pragma unroll
+      for (int i = 0; i < N2; ++i) o_mfma_d<T>(i % DT, v_frag(vbp, i), p_frag(pw, i / DT));
+      if (j + 1 < nact) qk_burst(par ^ 1, j + 1, sA, mA);
+      iter_end();
+    };
+
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    int j = 0;
+    while (j < nact) {
+      if ((j & 1) == 0) {
+        // fast loop: tiles j+1 and j+2 exist and need no mask; leave it (cold) as soon as a row max outgrows mref
+        while (j + 2 < fm && !trigger(mA)) {
+          fused(C0{}, j, sA, sB, mB);
+          if (trigger(mB)) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) sA[t] = sB[t];
+            mA = mB;
+            ++j;
+            break;
+          }
+          fused(C1{}, j + 1, sB, sA, mA);
+          j += 2;
+        }
+      }
+      slow(j);
+      ++j;
+    }
+    for (; j < nt; ++j) {                                // tiles of the block this wave does not touch
+      if (j + 2 < nt) dma_k(j + 2, j & 1);
+      if (j + 1 < nt) dma_v(j + 1, (j & 1) ^ 1);
+      iter_end();
+    }
+    if (p.trace && pass == 0) t_loop = __builtin_amdgcn_s_memtime();
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    const float l_tot = pair_sum(l_run);
+    const bool empty = !(l_tot > 0.f);
+    const float inv = empty ? 1.f : 1.f / l_tot;
+    if (p.lse != nullptr && hi == 0 && my_row < p.Nq) {
+      const float lse = empty ? INFINITY : (mref + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+      p.lse[(long long)bh * p.Nq + my_row] = lse;
+    }
+    if (F32OUT) {
+      float* obase = reinterpret_cast<float*>(p.o) + b * p.os_b + h * p.os_h;
+      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      const int ooff = my_row * (int)p.os_n * 4 + hi * 16;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        float o[16];
+        if (d == 0) o_read<0>(o, inv); else if (d == 1) o_read<1>(o, inv); else if (d == 2) o_read<2>(o, inv); else o_read<3>(o, inv);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v4 = {o[4 * g + 0], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, ooff + (d * 32 + g * 8) * 4, 0, 0);
+        }
+      }
+    } else {
+      T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
+      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      const int ooff = my_row * (int)p.os_n * 2 + hi * 8;
+      typedef __attribute__((ext_vector_type(4))) T t4;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        float o[16];
+        if (d == 0) o_read<0>(o, inv); else if (d == 1) o_read<1>(o, inv); else if (d == 2) o_read<2>(o, inv); else o_read<3>(o, inv);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          t4 v4 = {(T)o[4 * g + 0], (T)o[4 * g + 1], (T)o[4 * g + 2], (T)o[4 * g + 3]};
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, ooff + (d * 32 + g * 8) * 2, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (p.trace) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
+      t[0] = t_start; t[1] = t_pro; t[2] = t_loop; t[3] = t_end;
+      t[4] = (unsigned long long)nt_total;
+      t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);
+      t[6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);
+      t[7] = ((unsigned long long)bh << 32) | (unsigned)wi;
+    }
+  }
+}
+
+#undef KT
+#undef KS
+
+}  // namespace tfa

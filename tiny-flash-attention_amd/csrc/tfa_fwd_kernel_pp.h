@@ -28,6 +28,13 @@
 namespace tfa {
 
 constexpr int VF_VPRE_SHIFT = 8;   // bits 8..10: number of 32-wide d-tiles whose V fragments are read in the first half
+// Issue-port padding (tools/probe_issue.hip): a wave streaming back-to-back MFMAs re-arms the SIMD's VALU issue port
+// the moment it frees, so VALU work of the OTHER wave on that SIMD never gets in; an s_nop behind each MFMA leaves the gap.
+constexpr int VF_NOPQK_SHIFT = 16; // bits 16..20: 0 = off, n = "s_nop n-1" after every QK^T MFMA
+constexpr int VF_NOPPV_SHIFT = 21; // bits 21..25: same after every PV MFMA
+template <int N, typename ACC> static __device__ __forceinline__ void issue_gap(ACC& acc) {
+  if constexpr (N > 0) asm volatile("s_nop %1" : "+v"(acc) : "n"(N - 1));
+}
 
 // Barriers are inline asm (a memory clobber keeps LDS accesses on their side) followed by a full
 // scheduling barrier (keeps register-only VALU/MFMA work of the next half from being hoisted above).
@@ -208,7 +215,10 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel_pp(const KArgs p) {
 #pragma unroll
         for (int s = 0; s < DS; ++s)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) sacc[t] = E::mfma(kf[s][t], qf[s], sacc[t]);
+          for (int t = 0; t < 2; ++t) {
+            sacc[t] = E::mfma(kf[s][t], qf[s], sacc[t]);
+            issue_gap<(VF >> VF_NOPQK_SHIFT) & 31>(sacc[t]);
+          }
 
 #pragma unroll
         for (int d = 0; d < VPRE; ++d)
@@ -288,6 +298,7 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel_pp(const KArgs p) {
               vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
             }
             oacc[d] = E::mfma(__builtin_bit_cast(X8, vf), pk[s], oacc[d]);
+            issue_gap<(VF >> VF_NOPPV_SHIFT) & 31>(oacc[d]);
           }
         }
       }

@@ -6,6 +6,7 @@
 #include "tfa_fwd_kernel_dma.h"
 #include "tfa_fwd_kernel_swp.h"
 #include "tfa_fwd_kernel_w64.h"
+#include "tfa_fwd_kernel_il.h"
 
 namespace tfa {
 
@@ -41,6 +42,12 @@ static const Variant kVariants[] = {
     {"w64-pair (4 waves x 64 rows, one wave per SIMD, O accumulators pinned in AGPRs by inline-asm MFMA)", 4, VF_DMA | VF_W64 | VF_PAIR, 2},
     {"dma4-pair-2buf-ldsepi (O leaves through LDS as whole rows, 16-byte stores)", 4, VF_DMA | VF_PAIR | VF_2BUF | VF_LDSEPI, 1},
     {"dma8-pair-2buf-ldsepi", 8, VF_DMA | VF_PAIR | VF_2BUF | VF_LDSEPI, 1},
+    {"pp8-vpre4-gapqk8 (ping-pong + 8-cycle issue gap behind every QK^T MFMA)", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT) | (8 << VF_NOPQK_SHIFT), 1},
+    {"pp8-vpre4-gapqk8-gappv8", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT) | (8 << VF_NOPQK_SHIFT) | (8 << VF_NOPPV_SHIFT), 1},
+    {"pp8-vpre4-gapqk16", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT) | (16 << VF_NOPQK_SHIFT), 1},
+    {"il8-pair (issue-interleaved: every MFMA followed by its share of another tile's softmax; 8 waves)", 8, VF_DMA | VF_IL | VF_PAIR, 1},
+    {"il4-pair (issue-interleaved, 4 waves, two workgroups per CU)", 4, VF_DMA | VF_IL | VF_PAIR, 1},
+    {"il8-pair-dmaspread (LDS-DMA pieces issued between the first QK^T MFMAs)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 19;     // dma8-pair-2buf

@@ -1,0 +1,28 @@
+"""Timing-only ablations of the issue-interleaved kernel (variant 1000+mask, 2000+mask = DMA spread) on cfg4.
+Needs a library built with -DTFA_ABLATE (make -C tiny-flash-attention_amd/csrc EXTRA=-DTFA_ABLATE OBJDIR=... OUTDIR=...)
+and TFA_LIB pointing at it."""
+import ctypes as C, math, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tiny_flash_attention_amd import _lib, ops
+NAMES = {1: "NOEXP", 2: "NODMA", 4: "NOBARRIER", 8: "NOMAX", 16: "NOQK", 32: "NOPV", 64: "NOKREAD", 128: "NOVREAD"}
+dev = torch.device("cuda:0")
+B, H, N, D = 1, 16, 16384, 128
+mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(torch.bfloat16)
+q, k, v = mk(), mk(), mk()
+out = torch.empty_like(q); lse = torch.empty((B, H, N), dtype=torch.float32, device=dev)
+p = ops.make_params(q, k, v, out, lse, False, 1 / math.sqrt(D))
+s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+tiles = B * H * (N // 256) * (N // 64)
+masks = [0, 1, 2, 4, 8, 9, 80, 160, 11, 15, 6, 192, 201, 207, 240, 246]
+for base in (1000, 2000):
+    for rnd in range(2):
+        for m in masks:
+            _lib.set_variant(base + m)
+            ms = C.c_float()
+            _lib.check(_lib.lib().tfa_fwd_time(C.byref(p), 2, 5, s, C.byref(ms)))
+            name = "+".join(n for b, n in NAMES.items() if m & b) or "FULL"
+            if rnd == 1:
+                print(f"{base} mask {m:3d} {name:44s} {ms.value:7.3f} ms  ~{ms.value * 1e-3 * 2.1e9 / (tiles / 256):6.0f} cyc/tile/CU @2.1GHz")
+_lib.set_variant(-1)

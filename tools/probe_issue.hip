@@ -15,6 +15,11 @@ template <int OP> __device__ __forceinline__ void valu(float& x, f32x2& p, float
   if (OP == 2) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p) : "v"(p));
   if (OP == 3) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x) : "v"(s));
   if (OP == 4) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x) : "v"(s));
+  if (OP == 5) asm volatile("v_exp_f16 %0, %0" : "+v"(x));
+  if (OP == 6) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p) : "v"(p));
+  if (OP == 7) asm volatile("v_dot2_f32_bf16 %0, %1, %1, %0" : "+v"(x) : "v"(s));
+  if (OP == 8) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(x) : "v"(s));
+  if (OP == 9) asm volatile("v_exp_bf16 %0, %0" : "+v"(x));
 }
 
 // ROLE 1: MFMA with K VALU ops of kind OP after every MFMA and NOP s_nop-8-cycle pads; ROLE 2: VALU only (12 per "slot"); 0 idle
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, long long* tr, int iters
   if (r == 12345.678f) out[threadIdx.x] = r;
 }
 
-static const char* opn[] = {"v_fma_f32", "v_exp_f32", "v_pk_mul_f32", "v_max_f32", "v_cvt_pk_bf16_f32"};
+static const char* opn[] = {"v_fma_f32", "v_exp_f32", "v_pk_mul_f32", "v_max_f32", "v_cvt_pk_bf16_f32", "v_exp_f16", "v_pk_add_f32", "v_dot2_f32_bf16", "v_pk_mul_f16", "v_exp_bf16"};
 template <int K, int OP, int NOPS, int BROLE> void run(float* d, long long* tr) {
   const int it = 10000;
   k<K, OP, NOPS, BROLE><<<256, 512>>>(d, tr, it);
@@ -90,7 +95,15 @@ int main() {
   run<4, 2, 0, 0>(d, tr); run<8, 2, 0, 0>(d, tr); run<12, 2, 0, 0>(d, tr);
   run<4, 3, 0, 0>(d, tr); run<8, 3, 0, 0>(d, tr);
   run<4, 4, 0, 0>(d, tr); run<8, 4, 0, 0>(d, tr);
+  run<4, 5, 0, 0>(d, tr); run<8, 5, 0, 0>(d, tr);
+  run<4, 6, 0, 0>(d, tr); run<8, 6, 0, 0>(d, tr);
+  run<4, 7, 0, 0>(d, tr); run<8, 7, 0, 0>(d, tr);
+  run<4, 8, 0, 0>(d, tr); run<8, 8, 0, 0>(d, tr);
+#ifdef HAVE_EXP_BF16
+  run<4, 9, 0, 0>(d, tr); run<8, 9, 0, 0>(d, tr);
+#endif
   printf("== (a2) two such waves per SIMD\n");
+  run<6, 0, 0, 1>(d, tr); run<4, 5, 0, 1>(d, tr); run<8, 5, 0, 1>(d, tr); run<8, 7, 0, 1>(d, tr); run<8, 6, 0, 1>(d, tr);
   run<0, 0, 0, 1>(d, tr); run<4, 0, 0, 1>(d, tr); run<8, 0, 0, 1>(d, tr); run<12, 0, 0, 1>(d, tr);
   run<4, 1, 0, 1>(d, tr); run<8, 1, 0, 1>(d, tr);
   printf("== (b) other wave issues VALU (6 per slot); MFMA wave pads with s_nop 7 (8 cycles each)\n");
