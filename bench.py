@@ -81,8 +81,8 @@ def cpu_baseline(B, H, N, D, causal, target_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (-1 = library default)")
     ap.add_argument("--gather", action="store_true", help="also all-gather the output shards over RCCL")

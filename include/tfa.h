@@ -117,6 +117,12 @@ int tfa_fwd_bhnd_f32out(const void* q, const void* k, const void* v, float* out,
 /* Validate *p without launching; on success optionally reports the launch geometry. */
 int tfa_fwd_plan(const tfa_fwd_params* p, int* grid, int* block, int* lds_bytes);
 
+/* The kernel variant tfa_fwd would run for *p (>= 0; the forced one if tfa_set_variant is active), or a
+ * negative TFA_ERR_* code.  The parity tests use it to pick the matching same-rounding-points emulation:
+ * variants named "il..." keep a lazily re-based row reference instead of the exact running max
+ * (oracle/oracle.py: tiled_emulation_lazy), all others follow main_torch_only.py:240-257 exactly. */
+int tfa_fwd_variant(const tfa_fwd_params* p);
+
 /* Time `iters` back-to-back launches of *p with HIP events recorded on `stream`
  * (after `warmup` untimed launches).  Writes the average milliseconds per launch.
  * Synchronises `stream`.  Used by bench.py for the roofline numbers. */

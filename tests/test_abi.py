@@ -63,9 +63,12 @@ def test_plan_geometry():
     _lib.set_variant(15)  # persistent: one workgroup per CU walks the 1024 work items
     st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
     assert st == 0 and block == 512 and grid == 256
-    _lib.set_variant(-1)  # automatic: causal N=4096 -> 128-row blocks, two LDS buffers, paired
+    _lib.set_variant(-1)  # automatic: headline shape -> issue-interleaved kernel, 256-row blocks paired, 2 K + 2 V buffers
     st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
-    assert st == 0 and block == 256 and grid == 4 * 32 * 16 and lds == 4 * 64 * 128 * 2
+    assert st == 0 and block == 512 and grid == 4 * 32 * 8 and lds == 4 * 64 * 128 * 2
+    # automatic, small grid (BASELINE config 2) -> 128-row blocks, two 4-wave workgroups per CU
+    st, grid, block, lds = plan(_params(B=4, H=8, Hk=8, Nq=1024, Nk=1024, D=64, dtype=_lib.TFA_F16))
+    assert st == 0 and block == 256 and grid == 4 * 8 * 4 and lds == 4 * 64 * 64 * 2
     _lib.set_variant(4)   # causal blocks paired: ceil(16/2) work items per head
     st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
     assert st == 0 and block == 512 and grid == 4 * 32 * 8
@@ -122,3 +125,71 @@ def test_operator_error_behaviour_without_gpu():
     # all five arguments are positional in the reference binding (no py::arg): too few -> TypeError
     with pytest.raises(TypeError):
         tfa.flash_attention_v2_cutlass(q, q, q)
+
+
+def test_variant_selection_is_introspectable_without_gpu():
+    # big grids -> the issue-interleaved kernel (lazy row reference), small grids -> 128-row-block DMA kernel
+    big = _lib.variant_for(4, 32, 32, 4096, 4096, 128, True)
+    small = _lib.variant_for(4, 8, 8, 1024, 1024, 64, False, _lib.TFA_F16)
+    assert _lib.variant_name(big).startswith("il8") and _lib.lazy_reference(big)
+    assert _lib.variant_name(small).startswith("dma4") and not _lib.lazy_reference(small)
+    _lib.set_variant(19)
+    try:
+        assert _lib.variant_for(4, 32, 32, 4096, 4096, 128, True) == 19     # a forced variant is reported as such
+    finally:
+        _lib.set_variant(-1)
+    with pytest.raises(_lib.TfaError):
+        _lib.variant_for(1, 1, 1, 16, 16, 96, False)                         # unsupported head dim
+
+
+def test_il_kernels_leave_the_pinned_accumulator_registers_alone():
+    """tfa_fwd_kernel_il.h keeps O in v[192:255] by hand and caps the compiler at 192 VGPRs; if the cap is ever
+    ignored (it was, once: LLVM doubles amdgpu-num-vgpr on gfx90a+), compiler-allocated code tramples O.  Disassemble
+    the library: inside fwd_kernel_il* only v_mfma (acc in/out), 'v_mov_b32 vN, 0' and 'v_mul_f32' may touch v192+."""
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    if not (os.path.exists(objdump) and os.path.exists(bundler)):
+        pytest.skip("ROCm LLVM tools not present")
+    import tempfile
+
+    objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    dis = ""
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        r = subprocess.run([objcopy, f"--dump-section=.hip_fatbin={fat}", _lib.LIB_PATH], capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(fat):
+            pytest.skip(f"cannot dump .hip_fatbin: {r.stderr[:200]}")
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob)]
+        assert starts, "no offload bundles in .hip_fatbin"
+        for i, a in enumerate(starts):                     # one bundle per translation unit
+            b = starts[i + 1] if i + 1 < len(starts) else len(blob)
+            part, co = os.path.join(td, f"b{i}.bin"), os.path.join(td, f"b{i}.co")
+            open(part, "wb").write(blob[a:b])
+            r = subprocess.run([bundler, "--type=o", "--unbundle", f"--input={part}", f"--output={co}",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], capture_output=True, text=True)
+            assert r.returncode == 0 and os.path.getsize(co) > 0, r.stderr[:300]
+            dis += subprocess.run([objdump, "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+    cur, seen, bad = None, 0, []
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            cur = m.group(1)
+            continue
+        if not cur or "fwd_kernel_il" not in cur:
+            continue
+        text = line.split("//")[0]
+        regs = [int(x) for x in re.findall(r"\bv(\d+)\b", text)]
+        regs += [int(hi) for _, hi in re.findall(r"v\[(\d+):(\d+)\]", text)]
+        if not regs or max(regs) < 192:
+            continue
+        seen += 1
+        op = text.split()[0] if text.split() else ""
+        ok = op.startswith("v_mfma_f32_32x32x16") or op == "v_mul_f32_e32" or (op == "v_mov_b32_e32" and text.rstrip().endswith(", 0"))
+        if not ok:
+            bad.append(f"{cur[:60]}: {text.strip()}")
+    assert seen > 0, "no fwd_kernel_il code found in the library"
+    assert not bad, "compiler-allocated use of the pinned O registers:\n" + "\n".join(bad[:10])

@@ -16,6 +16,7 @@ SYMBOLS = (
     "tfa_fwd_bhnd",
     "tfa_fwd_bhnd_f32out",
     "tfa_fwd_plan",
+    "tfa_fwd_variant",
     "tfa_fwd_time",
     "tfa_set_variant",
     "tfa_get_variant",
@@ -90,6 +91,8 @@ def lib():
     L.tfa_set_variant.restype = C.c_int
     L.tfa_set_variant.argtypes = [C.c_int]
     L.tfa_get_variant.restype = C.c_int
+    L.tfa_fwd_variant.restype = C.c_int
+    L.tfa_fwd_variant.argtypes = [P]
     L.tfa_num_variants.restype = C.c_int
     L.tfa_variant_name.restype = C.c_char_p
     L.tfa_variant_name.argtypes = [C.c_int]
@@ -124,3 +127,26 @@ def num_variants():
 
 def variant_name(v):
     return lib().tfa_variant_name(int(v)).decode()
+
+
+def variant_for(B, H, Hk, Nq, Nk, D, is_causal, dtype=TFA_BF16):
+    """The variant tfa_fwd would run for a contiguous (B,H,N,D) problem of these sizes (no GPU needed)."""
+    p = TfaFwdParams()
+    p.q = p.k = p.v = p.out = 0x1000           # never dereferenced: tfa_fwd_variant only validates and plans
+    p.lse = None
+    p.B, p.H, p.Hk, p.Nq, p.Nk, p.D = B, H, Hk, Nq, Nk, D
+    for name, n, h in (("q_stride", Nq, H), ("k_stride", Nk, Hk), ("v_stride", Nk, Hk), ("o_stride", Nq, H)):
+        arr = getattr(p, name)
+        arr[0], arr[1], arr[2] = h * n * D, n * D, D
+    p.softmax_scale = 1.0
+    p.is_causal = 1 if is_causal else 0
+    p.dtype = p.out_dtype = dtype
+    v = lib().tfa_fwd_variant(C.byref(p))
+    if v < 0:
+        check(v)
+    return v
+
+
+def lazy_reference(v):
+    """True for the variants that keep a lazily re-based row reference instead of the exact running max."""
+    return variant_name(v).startswith("il")

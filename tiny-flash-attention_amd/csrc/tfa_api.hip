@@ -44,9 +44,9 @@ int pick_variant(const tfa_fwd_params* p) {
   // are enough of them to fill 256 CUs and no causal diagonal; 128-row blocks (two 4-wave workgroups per
   // CU) waste less of the causal diagonal and fill the chip on small problems (BASELINE config 2:
   // B4 H8 N1024 has only 128 blocks of 256 rows).
+  // The issue-interleaved kernel (tfa_fwd_kernel_il.h) wins wherever the grid fills the chip (+5..11% at D=128).
   const long long blocks256 = (long long)p->B * p->H * ((p->Nq + 255) / 256);
   if (blocks256 < 512) return tfa::kSmallGridVariant;
-  if (p->is_causal && p->Nq <= 8192) return tfa::kCausalVariant;
   return tfa::kDefaultVariant;
 }
 
@@ -185,6 +185,13 @@ int tfa_fwd_plan(const tfa_fwd_params* p, int* grid, int* block, int* lds_bytes)
   if (block) *block = g.block;
   if (lds_bytes) *lds_bytes = g.lds;
   return TFA_OK;
+}
+
+int tfa_fwd_variant(const tfa_fwd_params* p) {
+  tfa::LaunchGeom g = {0, 0, 0};
+  const int st = run(p, nullptr, &g, true);
+  if (st != 0) return st > 0 ? TFA_ERR_SHAPE : st;
+  return pick_variant(p);
 }
 
 int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, float* avg_ms) {

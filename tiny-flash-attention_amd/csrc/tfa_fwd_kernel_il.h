@@ -44,14 +44,14 @@ template <typename T> struct MfmaName;
 template <> struct MfmaName<__bf16> { static constexpr bool bf = true; };
 template <> struct MfmaName<_Float16> { static constexpr bool bf = false; };
 
-// O[d tile DI] += A.B.  "s_nop 1": a VALU write of an A/B operand needs 2 wait states before an MFMA reads it and the
-// compiler cannot see that this asm is an MFMA.
+// O[d tile DI] += A.B.  A VALU write of an A/B operand needs 2 wait states before an MFMA reads it and the compiler
+// cannot see that this asm is an MFMA: every caller packs P at least one whole MFMA slot before the MFMA that reads it.
 #define TFA_PV_CASE(DI, LO, HI, CLOB)                                                                                  \
   if constexpr (DI == (LO - 192) / 16) {                                                                               \
     if constexpr (MfmaName<T>::bf)                                                                                     \
-      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 v[" #LO ":" #HI "], %0, %1, v[" #LO ":" #HI "]" ::"v"(a), "v"(b) : CLOB); \
+      asm volatile("v_mfma_f32_32x32x16_bf16 v[" #LO ":" #HI "], %0, %1, v[" #LO ":" #HI "]" ::"v"(a), "v"(b) : CLOB); \
     else                                                                                                               \
-      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 v[" #LO ":" #HI "], %0, %1, v[" #LO ":" #HI "]" ::"v"(a), "v"(b) : CLOB);  \
+      asm volatile("v_mfma_f32_32x32x16_f16 v[" #LO ":" #HI "], %0, %1, v[" #LO ":" #HI "]" ::"v"(a), "v"(b) : CLOB);  \
   }
 template <typename T, int DI, typename X8> static __device__ __forceinline__ void o_mfma(X8 a, X8 b) {
   TFA_PV_CASE(DI, 192, 207, TFA_O_CLOB0)
@@ -110,6 +110,14 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   constexpr int N2 = 4 * DT;                       // PV MFMAs per tile
   constexpr int NE1 = 21;                          // softmax elements (of 32 per lane) handled in part 1
   constexpr int PFK = 2, PFV = 2;                  // fragment read-ahead, in MFMAs
+  // MFMA slot (0..N1+N2-1) in which softmax element e (0..31) is summed and packed; its exp2 is issued one slot and its
+  // scale/subtract two slots earlier.  P slot s (elements 8s..8s+7) feeds PV MFMAs N1+DT*s.., so it must be packed in
+  // an EARLIER slot than N1+DT*s (also the distance the asm MFMA needs after a VALU write of its operand).
+  auto slot_of_elem = [](int e) constexpr -> int {
+    return 1 + (e < NE1 ? e * N1 / NE1 : N1 + (e - NE1) * (3 * DT - 1) / (32 - NE1));
+  };
+  static_assert(slot_of_elem(7) < N1 && slot_of_elem(15) < N1 + DT && slot_of_elem(23) < N1 + 2 * DT && slot_of_elem(31) < N1 + 3 * DT,
+                "a P slot is packed too late for the PV MFMA that reads it");
 #ifndef TFA_IL_QKSPLIT
 #define TFA_IL_QKSPLIT 0
 #endif
@@ -294,6 +302,27 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         ev_hold = ev;
       }
     };
+    // The same element split into three stages that the fast path issues in three DIFFERENT MFMA slots (fma two slots
+    // ahead, exp2 one slot ahead, sum/pack in the element's own slot): a wave issues in order, so a chain
+    // fma -> exp -> add inside one slot would stall on every result; staged, all VALU work of a slot is independent.
+    auto st_fma = [&](int e, const f32x16 (&s)[2], float msc, float (&xs)[32]) {
+      const int slot = e >> 3, t = slot >> 1, r = (slot & 1) * 8 + (e & 7);
+      xs[e] = fmaf(s[t][r], sc, -msc);
+      asm volatile("" : "+v"(xs[e]));
+    };
+    auto st_exp = [&](int e, float (&xs)[32]) {
+      xs[e] = fast_exp2(xs[e]);
+      asm volatile("" : "+v"(xs[e]));
+    };
+    auto st_sum = [&](int e, float (&xs)[32], float (&lsum)[4], unsigned (&pw)[16]) {
+      lsum[e & 3] += xs[e];
+      asm volatile("" : "+v"(lsum[e & 3]));
+      if (e & 1) {
+        const t2 w = {(T)xs[e - 1], (T)xs[e]};
+        pw[e >> 1] = __builtin_bit_cast(unsigned, w);
+        asm volatile("" : "+v"(pw[e >> 1]));
+      }
+    };
     auto p_frag = [&](const unsigned (&pw)[16], int slot) -> X8 {
       const u32x4 w = {pw[4 * slot], pw[4 * slot + 1], pw[4 * slot + 2], pw[4 * slot + 3]};
       return __builtin_bit_cast(X8, w);
@@ -371,11 +400,26 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       constexpr int KB = PAR ^ 1;
       const char* vbp = vl + PAR * TILE_BYTES;
       unsigned pw[16];
-      float ev_hold = 0.f;
+      float xs[32];
       float lsum[4] = {0.f, 0.f, 0.f, 0.f};
       X8 kf[N1], vf[N2];
 #pragma unroll
       for (int i = 0; i < PFK; ++i) kf[i] = k_frag(KB, i);
+      // global MFMA slot g = 0..N1+N2-1; element e is summed/packed in slot SC(e), exponentiated in SC(e)-1, scaled in SC(e)-2
+      auto soft_slot = [&](int g) {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+          const int sc_e = slot_of_elem(e);
+          const int sb_e = sc_e - 1, sa_e = sc_e >= 2 ? sc_e - 2 : 0;
+          if (AB & ILAB_NOEXP) {
+            if (sc_e == g && (e & 1)) pw[e >> 1] = __builtin_bit_cast(unsigned, scur[e >> 4][e & 15]);
+          } else {
+            if (sa_e == g) st_fma(e, scur, msc, xs);
+            if (sb_e == g) st_exp(e, xs);
+            if (sc_e == g) st_sum(e, xs, lsum, pw);
+          }
+        }
+      };
       __builtin_amdgcn_sched_barrier(0);
       // part 1
 #pragma unroll
@@ -396,12 +440,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
           if (i < PPW) dma_v1(j + 1, PAR ^ 1, i);
           else if (i < 2 * PPW) { if (issue_k) dma_k1(j + 2, PAR, i - PPW); }
         }
-#pragma unroll
-        for (int e = 0; e < NE1; ++e)
-          if (e * N1 / NE1 == i) {
-            if (AB & ILAB_NOEXP) { if (e & 1) pw[e >> 1] = __builtin_bit_cast(unsigned, scur[0][e >> 1]); }
-            else soft_elem(e, scur, msc, lsum, pw, ev_hold);
-          }
+        soft_slot(i);
         __builtin_amdgcn_sched_barrier(0);
       }
       // part 2
@@ -411,12 +450,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         if (i + PFV < N2) vf[i + PFV] = (AB & ILAB_NOVREAD) ? vf[(i + PFV) % PFV] : v_frag(vbp, i + PFV);
         if (!(AB & ILAB_NOPV)) o_mfma_d<T>(i % DT, vf[i], p_frag(pw, i / DT));
         else asm volatile("" ::"v"(vf[i]), "v"(pw[(i / DT) * 4]), "v"(pw[(i / DT) * 4 + 1]), "v"(pw[(i / DT) * 4 + 2]), "v"(pw[(i / DT) * 4 + 3]));
-#pragma unroll
-        for (int e = NE1; e < 32; ++e)
-          if ((e - NE1) * (3 * DT) / (32 - NE1) == i) {
-            if (AB & ILAB_NOEXP) { if (e & 1) pw[e >> 1] = __builtin_bit_cast(unsigned, scur[1][e >> 1]); }
-            else soft_elem(e, scur, msc, lsum, pw, ev_hold);
-          }
+        soft_slot(N1 + i);
 #pragma unroll
         for (int q = 0; q < 16; ++q)               // 16 pairs of S(j+1) values -> one v_max3 each
           if (q * N2 / 16 == i && !(AB & ILAB_NOMAX)) {

@@ -50,9 +50,8 @@ static const Variant kVariants[] = {
     {"il8-pair-dmaspread (LDS-DMA pieces issued between the first QK^T MFMAs)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 19;     // dma8-pair-2buf
-constexpr int kCausalVariant = 17;      // dma4-pair-2buf (128-row query blocks, two workgroups per CU)
-constexpr int kSmallGridVariant = 17;
+constexpr int kDefaultVariant = 28;     // il8-pair-dmaspread
+constexpr int kSmallGridVariant = 17;   // dma4-pair-2buf (128-row query blocks, two workgroups per CU)
 
 struct LaunchGeom {
   int grid, block, lds;

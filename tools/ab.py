@@ -27,7 +27,8 @@ def quick_check(variant):
                                                (torch.bfloat16, 1, 2, 512, 128, False, None, None), (torch.float16, 2, 2, 520, 64, True, None, None)):
         q, k, v = O.make_inputs(B, H, N, D, dt, seed=3, Hk=Hk, Nk=Nk)
         sc = 1 / math.sqrt(D)
-        ref, lref = O.tiled_emulation(q, k, v, causal, sc, 64, return_lse=True)
+        emu = O.tiled_emulation_lazy if _lib.variant_name(variant).startswith('il') else O.tiled_emulation
+        ref, lref = emu(q, k, v, causal, sc, 64, return_lse=True)
         _lib.set_variant(variant)
         o32, lse = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc, out_f32=True)
         o16, _ = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc)
