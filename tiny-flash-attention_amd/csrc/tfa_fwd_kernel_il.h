@@ -59,6 +59,18 @@ template <typename T, int DI, typename X8> static __device__ __forceinline__ voi
   TFA_PV_CASE(DI, 224, 239, TFA_O_CLOB2)
   TFA_PV_CASE(DI, 240, 255, TFA_O_CLOB3)
 }
+// S accumulators of the fast path: the MFMA is inline asm only so that it stays the FIRST instruction of its slot (a
+// builtin MFMA may be scheduled behind the slot's VALU work, which then delays the matrix pipe instead of hiding under
+// it).  The results are first read by VALU code at least two MFMA issues later (row max in part 2), which covers
+// the MFMA-write -> VALU-read distance the compiler cannot insert for an asm.
+template <typename T, typename X8> static __device__ __forceinline__ void s_mfma0(f32x16& c, X8 a, X8 b) {
+  if constexpr (MfmaName<T>::bf) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+}
+template <typename T, typename X8> static __device__ __forceinline__ void s_mfma(f32x16& c, X8 a, X8 b) {
+  if constexpr (MfmaName<T>::bf) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
 template <typename T, typename X8> static __device__ __forceinline__ void o_mfma_d(int d, X8 a, X8 b) {   // d folds to a constant
   if (d == 0) o_mfma<T, 0>(a, b);
   else if (d == 1) o_mfma<T, 1>(a, b);
@@ -108,13 +120,29 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   constexpr int DT = D / 32;
   constexpr int N1 = 2 * DS;                       // QK^T MFMAs per tile
   constexpr int N2 = 4 * DT;                       // PV MFMAs per tile
-  constexpr int NE1 = 21;                          // softmax elements (of 32 per lane) handled in part 1
-  constexpr int PFK = 2, PFV = 2;                  // fragment read-ahead, in MFMAs
+#ifndef TFA_IL_NE1
+#define TFA_IL_NE1 21
+#endif
+#ifndef TFA_IL_PF
+#define TFA_IL_PF 2
+#endif
+  constexpr int NE1 = TFA_IL_NE1;                  // softmax elements (of 32 per lane) summed/packed during part 1
+  constexpr int PFK = TFA_IL_PF, PFV = TFA_IL_PF;  // fragment read-ahead, in MFMAs
+#ifndef TFA_IL_UNIFORM
+#define TFA_IL_UNIFORM 0
+#endif
+#ifndef TFA_IL_ASMQK
+#define TFA_IL_ASMQK 0
+#endif
   // MFMA slot (0..N1+N2-1) in which softmax element e (0..31) is summed and packed; its exp2 is issued one slot and its
   // scale/subtract two slots earlier.  P slot s (elements 8s..8s+7) feeds PV MFMAs N1+DT*s.., so it must be packed in
   // an EARLIER slot than N1+DT*s (also the distance the asm MFMA needs after a VALU write of its operand).
   auto slot_of_elem = [](int e) constexpr -> int {
+#if TFA_IL_UNIFORM
+    return 1 + e * (N1 + 3 * DT - 1) / 32;           // evenly over the slots before the last P slot is consumed
+#else
     return 1 + (e < NE1 ? e * N1 / NE1 : N1 + (e - NE1) * (3 * DT - 1) / (32 - NE1));
+#endif
   };
   static_assert(slot_of_elem(7) < N1 && slot_of_elem(15) < N1 + DT && slot_of_elem(23) < N1 + 2 * DT && slot_of_elem(31) < N1 + 3 * DT,
                 "a P slot is packed too late for the PV MFMA that reads it");
@@ -207,7 +235,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
   const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
   const float sc = p.scale_log2;
-  int nt_total = 0;
+  int nt_total = 0, n_slow = 0;
 
   const int npass = PAIR ? ((p.nmb - 1 - wi) != wi ? 2 : 1) : 1;
 #pragma nounroll
@@ -380,7 +408,10 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tt][r]);
       mout = pair_max(mx);
     };
-    if (nact > 0) qk_burst(0, 0, sA, mA);
+    if (nact > 0) {
+      qk_burst(0, 0, sA, mA);
+      mref = fmaxf(mref, mA * sc);                       // first re-base for free: O = 0 and l = 0 so far
+    }
     // K buffer 0 is refilled with K(2) at the top of iteration 0: every wave must be done with K(0)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -429,12 +460,20 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         if (AB & ILAB_NOQK) {
           if (i < 2) asm volatile("" : "+v"(snext[i]));
         } else if (KS(i) == 0) {                           // first k-slot of a key block: C = 0 (inline constant)
+#if TFA_IL_ASMQK
+          s_mfma0<T>(snext[KT(i)], kf[i], qf[KS(i)]);
+#else
           f32x16 z;
 #pragma unroll
           for (int r = 0; r < 16; ++r) z[r] = 0.f;
           snext[KT(i)] = E::mfma(kf[i], qf[KS(i)], z);
+#endif
         } else {
+#if TFA_IL_ASMQK
+          s_mfma<T>(snext[KT(i)], kf[i], qf[KS(i)]);
+#else
           snext[KT(i)] = E::mfma(kf[i], qf[KS(i)], snext[KT(i)]);
+#endif
         }
         if (SPREAD && !(AB & ILAB_NODMA)) {         // 2*PPW DMA pieces spread over the first MFMAs, one per MFMA
           if (i < PPW) dma_v1(j + 1, PAR ^ 1, i);
@@ -464,49 +503,41 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       if (AB & ILAB_NOBARRIER) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else iter_end();
     };
-    // ---- slow path: any tile (first, masked, last, rescale needed); S(j) in sA, runtime buffer parity ----------
-    auto slow = [&](int j) {
+    // ---- slow path: any tile (masked, last, re-base needed).  S(j) is in scur, S(j+1) goes to snext ------------------
+    auto slow = [&](int j, f32x16 (&scur)[2], float mcur, f32x16 (&snext)[2], float& mnext) {
       const int par = j & 1;
+      ++n_slow;
       if (j + 2 < nt) dma_k(j + 2, par);
       if (j + 1 < nt) dma_v(j + 1, par ^ 1);
-      rescale_if_needed(mA);
+      rescale_if_needed(mcur);
       const float msc = mref;
       const char* vbp = vl + par * TILE_BYTES;
       unsigned pw[16];
       float ev_hold = 0.f;
       float lsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 32; ++e) soft_elem(e, sA, msc, lsum, pw, ev_hold);
+      for (int e = 0; e < 32; ++e) soft_elem(e, scur, msc, lsum, pw, ev_hold);
       l_run += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
 #pragma unroll
       for (int i = 0; i < N2; ++i) o_mfma_d<T>(i % DT, v_frag(vbp, i), p_frag(pw, i / DT));
-      if (j + 1 < nact) qk_burst(par ^ 1, j + 1, sA, mA);
+      if (j + 1 < nact) qk_burst(par ^ 1, j + 1, snext, mnext);
       iter_end();
     };
 
+    // S(j) lives in sA for even j and in sB for odd j, on both paths, so the paths alternate freely without copies.
+    // Tile j takes the fast path when tile j+1 exists and needs no mask and no row max of tile j has outgrown mref.
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
-    int j = 0;
-    while (j < nact) {
-      if ((j & 1) == 0) {
-        // fast loop: tiles j+1 and j+2 exist and need no mask; leave it (cold) as soon as a row max outgrows mref
-        while (j + 2 < fm && !trigger(mA)) {
-          fused(C0{}, j, sA, sB, mB);
-          if (trigger(mB)) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) sA[t] = sB[t];
-            mA = mB;
-            ++j;
-            break;
-          }
-          fused(C1{}, j + 1, sB, sA, mA);
-          j += 2;
-        }
-      }
-      slow(j);
-      ++j;
+#pragma nounroll
+    for (int j = 0; j < nact; j += 2) {
+      if (j + 1 < fm && !trigger(mA)) fused(C0{}, j, sA, sB, mB);
+      else slow(j, sA, mA, sB, mB);
+      if (j + 1 >= nact) break;
+      if (j + 2 < fm && !trigger(mB)) fused(C1{}, j + 1, sB, sA, mA);
+      else slow(j + 1, sB, mB, sA, mA);
     }
-    for (; j < nt; ++j) {                                // tiles of the block this wave does not touch
+#pragma nounroll
+    for (int j = nact; j < nt; ++j) {                    // tiles of the block this wave does not touch
       if (j + 2 < nt) dma_k(j + 2, j & 1);
       if (j + 1 < nt) dma_v(j + 1, (j & 1) ^ 1);
       iter_end();
@@ -559,7 +590,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     if (tid == 0) {
       unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
       t[0] = t_start; t[1] = t_pro; t[2] = t_loop; t[3] = t_end;
-      t[4] = (unsigned long long)nt_total;
+      t[4] = (unsigned long long)nt_total | ((unsigned long long)n_slow << 32);   // wave 0's slow-path tiles in the high half
       t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);
       t[6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);
       t[7] = ((unsigned long long)bh << 32) | (unsigned)wi;

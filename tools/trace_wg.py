@@ -51,7 +51,10 @@ def trace(variant, cfg):
         b0 = t[m, 0].min()
         st[m] = t[m, 0] - b0
         en[m] = t[m, 3] - b0
-    pro, loop, epi, nt = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4]
+    pro, loop, epi, nt = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] & 0xFFFFFFFF
+    nslow = t[:, 4] >> 32
+    if nslow.max() > 0:
+        print(f"slow-path tiles of wave 0 per workgroup: mean {nslow.mean():.2f} max {nslow.max()} (of {nt.mean():.1f} tiles)")
     span = en.max()
     print(f"== variant {variant} {_lib.variant_name(variant)} | {cfg}: grid {g.value} block {b.value}")
     print(f"kernel span {span} cycles (max over XCCs of last end - first start); prologue mean {pro.mean():.0f} "
