@@ -155,6 +155,29 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
 
+    # sustained shader clock: one more launch with the per-workgroup trace on (s_memtime cycles over s_memrealtime
+    # 100 MHz ticks of every workgroup's life), right behind the timed region so the clock is the steady-state one
+    clk_mhz = None
+    if rank == 0:
+        try:
+            g_, b_, l_ = C.c_int(), C.c_int(), C.c_int()
+            _lib.check(L.tfa_fwd_plan(pref, C.byref(g_), C.byref(b_), C.byref(l_)))
+            tb = torch.zeros((g_.value, 8), dtype=torch.int64, device=dev)
+            for _ in range(20):
+                step()
+            L.tfa_debug_set_trace(C.c_void_p(tb.data_ptr()))
+            _lib.check(L.tfa_fwd(pref, sptr))
+            torch.cuda.synchronize()
+            L.tfa_debug_set_trace(None)
+            tr = tb.cpu()
+            cyc, ticks = (tr[:, 3] - tr[:, 0]).double(), tr[:, 6].double()
+            ok = ticks > 0
+            if bool(ok.any()):
+                clk_mhz = float((cyc[ok] / ticks[ok] * 100.0).median())
+        except Exception:
+            L.tfa_debug_set_trace(None)
+            clk_mhz = None
+
     fl, by = C.c_double(), C.c_double()
     L.tfa_fwd_work(pref, C.byref(fl), C.byref(by))
     flops_step_rank = fl.value
@@ -204,6 +227,10 @@ def main():
                 "frac": achieved / PEAK_TFLOPS_BF16,
                 "traffic": traffic,
                 "launch_ms": ev_ms,
+                "nominal_clock_mhz": 2400.0,
+                "sustained_clock_mhz": clk_mhz,
+                "peak_at_sustained_clock": (PEAK_TFLOPS_BF16 * clk_mhz / 2400.0) if clk_mhz else None,
+                "frac_at_sustained_clock": (achieved / (PEAK_TFLOPS_BF16 * clk_mhz / 2400.0)) if clk_mhz else None,
                 "algorithmic_hbm_GBs": by.value / (ev_ms * 1e-3) / 1e9,
                 "hbm_frac": by.value / (ev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },

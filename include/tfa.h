@@ -136,9 +136,12 @@ int tfa_num_variants(void);
 const char* tfa_variant_name(int variant);
 
 /* Debug/profiling: when dev_buf != NULL every workgroup of subsequent launches writes 8 x uint64
- * {t_start, t_after_prologue, t_after_loop, t_end (shader cycles), n_kv_tiles, XCC_ID, HW_ID,
- * (bh<<32)|query_block} at dev_buf[8*workgroup_id ...]; the buffer must hold 64 B per workgroup
- * (tfa_fwd_plan reports the grid).  NULL (default) disables it. */
+ * {t_start, t_after_prologue, t_after_loop, t_end (shader cycles, s_memtime), n_kv_tiles (low 32 bits),
+ * XCC_ID | HW_ID << 32, the workgroup's life in 100 MHz s_memrealtime ticks, (bh<<32)|query_block}
+ * at dev_buf[8*workgroup_id ...]; the buffer must hold 64 B per workgroup (tfa_fwd_plan reports the
+ * grid).  (t_end - t_start) / ticks * 100 MHz is the shader clock the workgroup actually ran at:
+ * bench.py reports its median as the sustained clock next to the nominal 2.4 GHz.  NULL (default)
+ * disables it. */
 int tfa_debug_set_trace(void* dev_buf);
 
 /* Algorithmic work of *p: flops = 4*B*H*Nq*Nk*D (x1/2 when causal, the reference's

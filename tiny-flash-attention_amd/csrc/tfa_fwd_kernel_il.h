@@ -161,8 +161,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   char* const vl = smem + 2 * TILE_BYTES;          // V buffers 0,1
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-  unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
-  if (p.trace) t_start = __builtin_amdgcn_s_memtime();
+  unsigned long long t_start = 0, t_pro = 0, t_loop = 0, rt_start = 0;
+  if (p.trace) { rt_start = __builtin_amdgcn_s_memrealtime(); t_start = __builtin_amdgcn_s_memtime(); }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -419,8 +419,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 
     // ---- fast path: tile j (S in scur) -> O; S(j+1) and its row max -> snext, mnext.  One basic block. ---------
     // PAR = j & 1: K(j+1) is in K buffer PAR^1, V(j) in V buffer PAR; K(j+2) -> K buffer PAR, V(j+1) -> V buffer PAR^1.
-    auto fused = [&](auto par_c, int j, f32x16 (&scur)[2], f32x16 (&snext)[2], float& mnext) {
+    auto fused = [&](auto par_c, auto mask_c, int j, f32x16 (&scur)[2], f32x16 (&snext)[2], float& mnext) {
       constexpr int PAR = decltype(par_c)::value;
+      constexpr bool MASK = decltype(mask_c)::value;   // tile j+1 is the wave's masked (diagonal / ragged) tile
       constexpr bool SPREAD = (VF & VF_IL_DMASPREAD) != 0;
       const bool issue_k = (j + 2 < nt);
       if (!SPREAD && !(AB & ILAB_NODMA)) {
@@ -482,6 +483,13 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         soft_slot(i);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (MASK) {                                     // S(j+1) is complete (MFMA results: the s_nop covers the read distance)
+#if TFA_IL_ASMQK
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
+        apply_mask(j + 1, snext);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // part 2
       float mx = -INFINITY;
 #pragma unroll
@@ -525,16 +533,27 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     };
 
     // S(j) lives in sA for even j and in sB for odd j, on both paths, so the paths alternate freely without copies.
-    // Tile j takes the fast path when tile j+1 exists and needs no mask and no row max of tile j has outgrown mref.
+    // Tile j takes the fast path when tile j+1 exists and no row max of tile j has outgrown mref; if tile j+1 needs
+    // masking (at most the wave's last one or two tiles) the body with the mask between its two parts runs.
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
+    using MN = std::integral_constant<bool, false>;
+    using MY = std::integral_constant<bool, true>;
 #pragma nounroll
     for (int j = 0; j < nact; j += 2) {
-      if (j + 1 < fm && !trigger(mA)) fused(C0{}, j, sA, sB, mB);
-      else slow(j, sA, mA, sB, mB);
+      if (j + 1 < nact && !trigger(mA)) {
+        if (j + 1 < fm) fused(C0{}, MN{}, j, sA, sB, mB);
+        else fused(C0{}, MY{}, j, sA, sB, mB);
+      } else {
+        slow(j, sA, mA, sB, mB);
+      }
       if (j + 1 >= nact) break;
-      if (j + 2 < fm && !trigger(mB)) fused(C1{}, j + 1, sB, sA, mA);
-      else slow(j + 1, sB, mB, sA, mA);
+      if (j + 2 < nact && !trigger(mB)) {
+        if (j + 2 < fm) fused(C1{}, MN{}, j + 1, sB, sA, mA);
+        else fused(C1{}, MY{}, j + 1, sB, sA, mA);
+      } else {
+        slow(j + 1, sB, mB, sA, mA);
+      }
     }
 #pragma nounroll
     for (int j = nact; j < nt; ++j) {                    // tiles of the block this wave does not touch
@@ -591,8 +610,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
       t[0] = t_start; t[1] = t_pro; t[2] = t_loop; t[3] = t_end;
       t[4] = (unsigned long long)nt_total | ((unsigned long long)n_slow << 32);   // wave 0's slow-path tiles in the high half
-      t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);
-      t[6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);
+      t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63508) | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32);   // XCC_ID | HW_ID << 32
+      t[6] = __builtin_amdgcn_s_memrealtime() - rt_start;   // 100 MHz ticks over the same span as t[3] - t[0] shader cycles
       t[7] = ((unsigned long long)bh << 32) | (unsigned)wi;
     }
   }

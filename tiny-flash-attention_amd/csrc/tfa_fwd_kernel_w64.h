@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KArgs p) {
   char* const vl = smem + NBUF * TILE_BYTES;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-  unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
-  if (p.trace) t_start = __builtin_amdgcn_s_memtime();
+  unsigned long long t_start = 0, t_pro = 0, t_loop = 0, rt_start = 0;
+  if (p.trace) { rt_start = __builtin_amdgcn_s_memrealtime(); t_start = __builtin_amdgcn_s_memtime(); }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KArgs p) {
       unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
       t[0] = t_start; t[1] = t_pro; t[2] = t_loop; t[3] = t_end;
       t[4] = (unsigned long long)nt_total;
-      t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);
-      t[6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);
+      t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63508) | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32);   // XCC_ID | HW_ID << 32
+      t[6] = __builtin_amdgcn_s_memrealtime() - rt_start;   // 100 MHz ticks over the same span as t[3] - t[0] shader cycles
       t[7] = ((unsigned long long)bh << 32) | (unsigned)wi;
     }
   }

@@ -51,6 +51,7 @@ static const Variant kVariants[] = {
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 28;     // il8-pair-dmaspread
+constexpr int kShortCausalVariant = 27;  // il4-pair (128-row query blocks, two workgroups per CU)
 constexpr int kSmallGridVariant = 17;   // dma4-pair-2buf (128-row query blocks, two workgroups per CU)
 
 struct LaunchGeom {

@@ -17,7 +17,9 @@ from oracle import oracle as O  # noqa: E402
 
 CFG = {"cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096, 128, torch.bfloat16, False),
        "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg2": (4, 8, 1024, 64, torch.float16, False),
-       "cfg2c": (4, 8, 1024, 64, torch.float16, True), "cfg5": (8, 32, 4096, 128, torch.bfloat16, True)}
+       "cfg2c": (4, 8, 1024, 64, torch.float16, True), "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),
+       "d64": (4, 32, 4096, 64, torch.float16, False), "d64c": (4, 32, 4096, 64, torch.float16, True),
+       "n2k": (8, 32, 2048, 128, torch.bfloat16, True), "n1k": (16, 32, 1024, 128, torch.bfloat16, True)}
 dev = torch.device("cuda:0")
 
 

@@ -38,7 +38,9 @@ def trace(variant, cfg):
     _lib.lib().tfa_debug_set_trace(None)
     t = buf.cpu().numpy().astype(np.int64)
     xcc = t[:, 5] & 0xF
-    hw = t[:, 6]
+    hw = (t[:, 5] >> 32) & 0xFFFFFFFF
+    mhz = (t[:, 3] - t[:, 0]) / np.maximum(t[:, 6], 1) * 100.0
+    print(f"shader clock while the workgroups ran (s_memtime / s_memrealtime): median {np.median(mhz):.0f} MHz, p5 {np.percentile(mhz, 5):.0f}, p95 {np.percentile(mhz, 95):.0f}")
     cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5)   # cu_id | sh_id | se_id
     cuid = xcc * 256 + cu
     # s_memtime is per-XCC: normalise each XCC to its own first start
