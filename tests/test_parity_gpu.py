@@ -109,7 +109,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28])
+@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29])
 @pytest.mark.parametrize("dtype,B,H,N,D,causal", SHAPES)
 def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
     from tiny_flash_attention_amd import _lib
@@ -123,12 +123,20 @@ def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causa
         _lib.set_variant(-1)
 
 
-@pytest.mark.parametrize("Nq,Nk,causal", [(128, 384, True), (384, 128, True), (100, 333, False), (1, 1000, True), (257, 64, False)])
-def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal):
+@pytest.mark.parametrize("variant", [-1, 27, 28])     # automatic (small grid), and the two issue-interleaved kernels forced
+@pytest.mark.parametrize("Nq,Nk,causal", [(128, 384, True), (384, 128, True), (100, 333, False), (1, 1000, True), (257, 64, False),
+                                          (700, 1500, True), (1111, 1111, False)])
+def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
     # K/V heads < Q heads and Nq != Nk with the reference's bottom-right causal offset
     # (flash_attention_c/csrc/attn.cpp:121-124); (384,128,causal) has 256 EMPTY rows -> O=0, LSE=+inf
-    run_case(tfa, oracle, dev, torch.bfloat16, 1, 4, Nq, 128, causal, Hk=2, Nk=Nk, seed=7)
-    run_case(tfa, oracle, dev, torch.float16, 2, 6, Nq, 64, causal, Hk=1, Nk=Nk, seed=8)
+    from tiny_flash_attention_amd import _lib
+
+    _lib.set_variant(variant)
+    try:
+        run_case(tfa, oracle, dev, torch.bfloat16, 1, 4, Nq, 128, causal, Hk=2, Nk=Nk, seed=7)
+        run_case(tfa, oracle, dev, torch.float16, 2, 6, Nq, 64, causal, Hk=1, Nk=Nk, seed=8)
+    finally:
+        _lib.set_variant(-1)
 
 
 def test_baseline_cfg2_full(tfa, oracle, dev):
@@ -316,14 +324,21 @@ def test_long_context_cfg4_properties(tfa, dev):
     assert (out_k.float() - out[:, :2].float()).abs().max().item() <= 1e-2 * out.float().abs().max().item() + 2 ** -9
 
 
-def test_strided_bnhd_matches_bhnd(tfa, oracle, dev):
-    from tiny_flash_attention_amd import ops
+@pytest.mark.parametrize("variant", [-1, 27, 28])
+def test_strided_bnhd_matches_bhnd(tfa, oracle, dev, variant):
+    from tiny_flash_attention_amd import _lib, ops
 
     q, k, v = oracle.make_inputs(2, 8, 384, 128, torch.bfloat16, seed=5, Hk=2)
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
-    o_bhnd, l_bhnd = ops.flash_attn_fwd(qd, kd, vd, True, 0.09)
-    qt, kt, vt = (t.transpose(1, 2).contiguous() for t in (qd, kd, vd))     # (B,N,H,D) storage
-    o_bnhd, l_bnhd = ops.flash_attn_fwd(qt, kt, vt, True, 0.09, layout="bnhd")
+    _lib.set_variant(variant)
+    try:
+        o_bhnd, l_bhnd = ops.flash_attn_fwd(qd, kd, vd, True, 0.09)
+        qt, kt, vt = (t.transpose(1, 2).contiguous() for t in (qd, kd, vd))     # (B,N,H,D) storage
+        o_bnhd, l_bnhd = ops.flash_attn_fwd(qt, kt, vt, True, 0.09, layout="bnhd")
+        torch.cuda.synchronize()
+        check(oracle, o_bhnd, None, l_bhnd, q, k, v, True, 0.09, torch.bfloat16)
+    finally:
+        _lib.set_variant(-1)
     assert torch.equal(o_bnhd.transpose(1, 2), o_bhnd) and torch.equal(l_bnhd, l_bhnd)
 
 

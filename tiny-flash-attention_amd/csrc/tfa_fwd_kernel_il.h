@@ -28,6 +28,8 @@ namespace tfa {
 
 constexpr int VF_IL = 32768;        // issue-interleaved kernel (this file)
 constexpr int VF_IL_DMASPREAD = 65536;   // issue the LDS-DMA pieces between MFMAs of part 1 instead of at the top
+constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
+                                         // so the two waves of a SIMD never sit in an LDS-DMA issue stall at the same time
 
 // ---- O accumulators in hand-pinned registers v[192:255] ---------------------------------------------------------
 // The kernel is compiled with amdgpu_num_vgpr(96) (LLVM doubles the request on gfx90a+: 192 unified registers): the register allocator owns v0..v191 and never sees O.  With O as
@@ -423,6 +425,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       constexpr int PAR = decltype(par_c)::value;
       constexpr bool MASK = decltype(mask_c)::value;   // tile j+1 is the wave's masked (diagonal / ragged) tile
       constexpr bool SPREAD = (VF & VF_IL_DMASPREAD) != 0;
+      constexpr bool STAGGER = SPREAD && (VF & VF_IL_DMASTAGGER) != 0;
+      const bool late = STAGGER && wave >= NW / 2;
       const bool issue_k = (j + 2 < nt);
       if (!SPREAD && !(AB & ILAB_NODMA)) {
         if (issue_k) dma_k(j + 2, PAR);
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
           snext[KT(i)] = E::mfma(kf[i], qf[KS(i)], snext[KT(i)]);
 #endif
         }
-        if (SPREAD && !(AB & ILAB_NODMA)) {         // 2*PPW DMA pieces spread over the first MFMAs, one per MFMA
+        if (SPREAD && !(AB & ILAB_NODMA) && !(STAGGER && late)) {   // 2*PPW DMA pieces spread over the first MFMAs, one per MFMA
           if (i < PPW) dma_v1(j + 1, PAR ^ 1, i);
           else if (i < 2 * PPW) { if (issue_k) dma_k1(j + 2, PAR, i - PPW); }
         }
@@ -497,6 +501,10 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         if (i + PFV < N2) vf[i + PFV] = (AB & ILAB_NOVREAD) ? vf[(i + PFV) % PFV] : v_frag(vbp, i + PFV);
         if (!(AB & ILAB_NOPV)) o_mfma_d<T>(i % DT, vf[i], p_frag(pw, i / DT));
         else asm volatile("" ::"v"(vf[i]), "v"(pw[(i / DT) * 4]), "v"(pw[(i / DT) * 4 + 1]), "v"(pw[(i / DT) * 4 + 2]), "v"(pw[(i / DT) * 4 + 3]));
+        if (STAGGER && late && !(AB & ILAB_NODMA)) {
+          if (i < PPW) dma_v1(j + 1, PAR ^ 1, i);
+          else if (i < 2 * PPW) { if (issue_k) dma_k1(j + 2, PAR, i - PPW); }
+        }
         soft_slot(N1 + i);
 #pragma unroll
         for (int q = 0; q < 16; ++q)               // 16 pairs of S(j+1) values -> one v_max3 each

@@ -48,6 +48,7 @@ static const Variant kVariants[] = {
     {"il8-pair (issue-interleaved: every MFMA followed by its share of another tile's softmax; 8 waves)", 8, VF_DMA | VF_IL | VF_PAIR, 1},
     {"il4-pair (issue-interleaved, 4 waves, two workgroups per CU)", 4, VF_DMA | VF_IL | VF_PAIR, 1},
     {"il8-pair-dmaspread (LDS-DMA pieces issued between the first QK^T MFMAs)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD, 1},
+    {"il8-pair-dmastagger (waves 4-7 issue their LDS-DMA pieces behind the first PV MFMAs instead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_DMASTAGGER, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 28;     // il8-pair-dmaspread
