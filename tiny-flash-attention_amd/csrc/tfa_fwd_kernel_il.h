@@ -28,6 +28,8 @@ namespace tfa {
 
 constexpr int VF_IL = 32768;        // issue-interleaved kernel (this file)
 constexpr int VF_IL_DMASPREAD = 65536;   // issue the LDS-DMA pieces between MFMAs of part 1 instead of at the top
+constexpr int VF_IL_EPI = 262144;        // 16-bit O leaves through a separate LDS region as whole rows (16-byte coalesced stores)
+constexpr int VF_IL_PREF = 524288;       // the next pass's K(0)/V(0)/K(1)/Q are requested BEFORE this pass's epilogue
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
                                          // so the two waves of a SIMD never sit in an LDS-DMA issue stall at the same time
 
@@ -240,11 +242,35 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   int nt_total = 0, n_slow = 0;
 
   const int npass = PAIR ? ((p.nmb - 1 - wi) != wi ? 2 : 1) : 1;
+  constexpr bool EPI = (VF & VF_IL_EPI) != 0;
+  constexpr bool PREF = (VF & VF_IL_PREF) != 0;
+  X8 qf[DS];
+  auto block_of = [&](int pass) -> int {
+    if (PAIR) return pass == 0 ? (p.nmb - 1 - wi) : wi;
+    return CAUSAL ? (p.nmb - 1 - wi) : wi;
+  };
+  // requests for the start of query block mbx: K(0), V(0), K(1) by LDS-DMA and this lane's Q fragments
+  auto issue_prologue = [&](int mbx) {
+    const int q0x = mbx * BM;
+    int kve = p.Nk;
+    if (CAUSAL) {
+      const int lim = q0x + BM + shift;
+      kve = lim < kve ? lim : kve;
+    }
+    const int ntx = kve > 0 ? (kve + BN - 1) / BN : 0;
+    if (ntx > 0) dma_k(0, 0);
+    if (ntx > 0) dma_v(0, 0);
+    if (ntx > 1) dma_k(1, 1);
+    const int qoff = (q0x + wave * 32 + qi) * (int)p.qs_n * 2 + hi * 16;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, qoff + s * 32, 0, 0);
+      qf[s] = __builtin_bit_cast(X8, t);
+    }
+  };
 #pragma nounroll
   for (int pass = 0; pass < npass; ++pass) {
-    int mb;
-    if (PAIR) mb = pass == 0 ? (p.nmb - 1 - wi) : wi;
-    else mb = CAUSAL ? (p.nmb - 1 - wi) : wi;
+    const int mb = block_of(pass);
     const int q0 = mb * BM;
     int kv_end = p.Nk;
     if (CAUSAL) {
@@ -258,7 +284,6 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     const int my_row = wave_row0 + qi;
     const int wave_last_tile = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (nt - 1);
 
-    X8 qf[DS];
     float l_run = 0.f;
 
     auto k_frag = [&](int kbuf, int i) -> X8 {   // fragment of QK^T MFMA i: key block i/DS, k-slot i%DS
@@ -359,17 +384,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     };
 
     // ---- prologue: K(0), V(0), K(1) by DMA, Q fragments, S(0) and its row max -------------------------
-    if (nt > 0) dma_k(0, 0);
-    if (nt > 0) dma_v(0, 0);
-    if (nt > 1) dma_k(1, 1);
-    {
-      const int qoff = my_row * (int)p.qs_n * 2 + hi * 16;
-#pragma unroll
-      for (int s = 0; s < DS; ++s) {
-        u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, qoff + s * 32, 0, 0);
-        qf[s] = __builtin_bit_cast(X8, t);
-      }
-    }
+    if (!PREF || pass == 0) issue_prologue(mb);      // (with PREF the previous pass already asked for this block)
     o_zero<DT>();
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -572,6 +587,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     if (p.trace && pass == 0) t_loop = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue ---------------------------------------------------------------------------
+    // every wave is past the last tile's barrier: the K/V buffers and qf are free -> ask for the next pass's first tiles
+    // and Q now, so that their latency hides behind the normalisation and the stores below
+    if (PREF && pass + 1 < npass) issue_prologue(block_of(pass + 1));
     const float l_tot = pair_sum(l_run);
     const bool empty = !(l_tot > 0.f);
     const float inv = empty ? 1.f : 1.f / l_tot;
@@ -593,6 +611,42 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, ooff + (d * 32 + g * 8) * 4, 0, 0);
         }
       }
+    } else if (EPI) {
+      // A lane holds 4-element pieces of ONE row spread over 16 register groups: stored directly that is 16 eight-byte
+      // stores per lane, 32 different rows per instruction.  Instead the wave transposes its 32 x D tile through its own
+      // slice of the epilogue region (16-byte chunk index XOR row, as for K) and writes whole rows: 1 KiB contiguous per
+      // store instruction.  The region is separate from the tile buffers (which the next pass is already filling).
+      T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
+      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      typedef __attribute__((ext_vector_type(4))) T t4;
+      // (the lane ids go through an empty asm so that none of the 24 addresses below is loop-invariant: hoisted out of
+      // the pass loop they would stay live across the main loop and spill)
+      int qix = qi, lanex = lane;
+      asm volatile("" : "+v"(qix), "+v"(lanex));
+      char* const ow = smem + 4 * TILE_BYTES + wave * (32 * D * 2);
+      constexpr int CH = D / 8;                      // 16-byte chunks per row
+      const int osw = (CH == 16) ? (qix & 15) : (qix & 7);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        float o[16];
+        if (d == 0) o_read<0>(o, inv); else if (d == 1) o_read<1>(o, inv); else if (d == 2) o_read<2>(o, inv); else o_read<3>(o, inv);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          t4 v4 = {(T)o[4 * g + 0], (T)o[4 * g + 1], (T)o[4 * g + 2], (T)o[4 * g + 3]};
+          const int c = d * 4 + g;
+          *reinterpret_cast<u32x2*>(ow + qix * (D * 2) + ((c ^ osw) << 4) + (lanex >> 5) * 8) = __builtin_bit_cast(u32x2, v4);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slice: no barrier needed
+      constexpr int RPI = 64 / CH;                   // rows per store instruction (4 at D=128, 8 at D=64)
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int r = i * RPI + lanex / CH, cpos = lanex % CH;
+        const int c = cpos ^ ((CH == 16) ? (r & 15) : (r & 7));
+        u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
+        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, (wave_row0 + r) * (int)p.os_n * 2 + (c << 4), 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by this wave's next epilogue only
     } else {
       T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
       auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);

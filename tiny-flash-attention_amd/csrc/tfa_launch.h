@@ -49,9 +49,11 @@ static const Variant kVariants[] = {
     {"il4-pair (issue-interleaved, 4 waves, two workgroups per CU)", 4, VF_DMA | VF_IL | VF_PAIR, 1},
     {"il8-pair-dmaspread (LDS-DMA pieces issued between the first QK^T MFMAs)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD, 1},
     {"il8-pair-dmastagger (waves 4-7 issue their LDS-DMA pieces behind the first PV MFMAs instead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_DMASTAGGER, 1},
+    {"il8-pair-dmaspread-epi (O leaves through a separate LDS region as whole rows, 16-byte stores)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {"il8-pair-dmaspread-epi-pref (+ the next pass's first tiles and Q requested before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 28;     // il8-pair-dmaspread
+constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
 constexpr int kShortCausalVariant = 27;  // il4-pair (128-row query blocks, two workgroups per CU)
 constexpr int kSmallGridVariant = 17;   // dma4-pair-2buf (128-row query blocks, two workgroups per CU)
 
