@@ -128,6 +128,51 @@ int tfa_fwd_variant(const tfa_fwd_params* p);
  * Synchronises `stream`.  Used by bench.py for the roofline numbers. */
 int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, float* avg_ms);
 
+/* ---- backward ------------------------------------------------------------
+ * The reference has no backward pass; it saves softmax_lse for one ("LogSumExp save for backward",
+ * flash_attention_cutlass/csrc/flash_attention.cu:353-354, :614-623; tiny_flash_attn_triton.py:27-29).
+ * tfa_bwd consumes exactly what tfa_fwd produced: out and lse of the same q,k,v, and the upstream
+ * gradient dout (same shape/dtype as out), and writes dq (shape of q), dk, dv (shape of k, v; for
+ * grouped-query attention summed over the query heads of each kv head).  Same layout rules as tfa_fwd
+ * (strides in elements, unit stride along D, 16-byte aligned rows); grads are written in the input
+ * dtype, or in fp32 when grad_dtype == TFA_F32 (debug path for tolerance checks below one 16-bit ulp).
+ * `delta` is caller-provided scratch of B*H*Nq floats (rowsum(dout o out), filled by the call). */
+typedef struct tfa_bwd_params {
+  const void* q;
+  const void* k;
+  const void* v;
+  const void* out;
+  const void* dout;
+  const float* lse;      /* (B,H,Nq) contiguous, natural log, as written by tfa_fwd */
+  void* dq;
+  void* dk;
+  void* dv;
+  float* delta;          /* scratch, B*H*Nq floats */
+  int B, H, Hk, Nq, Nk, D;
+  int64_t q_stride[3];   /* batch, head, row (elements) */
+  int64_t k_stride[3];
+  int64_t v_stride[3];
+  int64_t o_stride[3];
+  int64_t do_stride[3];
+  int64_t dq_stride[3];
+  int64_t dk_stride[3];
+  int64_t dv_stride[3];
+  float softmax_scale;
+  int is_causal;
+  int dtype;             /* TFA_F16 / TFA_BF16: q,k,v,out,dout */
+  int grad_dtype;        /* == dtype, or TFA_F32 */
+} tfa_bwd_params;
+
+/* Launch delta + dQ + dK + dV kernels on `stream` (asynchronous). */
+int tfa_bwd(const tfa_bwd_params* p, void* stream);
+/* Validate *p without launching (no GPU needed). */
+int tfa_bwd_plan(const tfa_bwd_params* p);
+/* Algorithmic work of one call: flops = 2.5 x the forward's (5 GEMMs of 2*Nq*Nk*D each per head, halved
+ * when causal), bytes = q,k,v,out,dout read once + dq,dk,dv written once + lse. */
+int tfa_bwd_work(const tfa_bwd_params* p, double* flops, double* bytes);
+/* Time `iters` back-to-back tfa_bwd calls with HIP events on `stream` (after `warmup` untimed ones). */
+int tfa_bwd_time(const tfa_bwd_params* p, int warmup, int iters, void* stream, float* avg_ms);
+
 /* Kernel-variant selector for A/B measurement and bring-up.  -1 = automatic (default).
  * tfa_num_variants() variants exist; tfa_variant_name(i) describes variant i. */
 int tfa_set_variant(int variant);

@@ -227,6 +227,31 @@ def tiled_emulation_lazy(q, k, v, is_causal, softmax_scale, block_n=64, group=32
     return out
 
 
+def attn_bwd_reference(q, k, v, dout, is_causal, softmax_scale, dtype=torch.float64):
+    """Gradients of O = softmax(scale * Q K^T + mask) V w.r.t. q, k, v by autograd on the CPU in ``dtype``
+    (fp64 = ground truth) — the function the reference's forward implements (attn.cpp:35-98) differentiated;
+    the reference itself has no backward (it only saves the LSE for one, flash_attention.cu:353-354).
+    q (B,H,Nq,D), k/v (B,Hk,Nk,D) with H % Hk == 0 (dk, dv are summed over the query heads of a kv head);
+    causal mask bottom-right aligned (attn.cpp:121-124).  Returns (dq, dk, dv) in ``dtype``."""
+    qf = q.detach().cpu().to(dtype).requires_grad_(True)
+    kf = k.detach().cpu().to(dtype).requires_grad_(True)
+    vf = v.detach().cpu().to(dtype).requires_grad_(True)
+    B, H, Nq, D = qf.shape
+    Hk, Nk = kf.shape[1], kf.shape[2]
+    ke = kf.repeat_interleave(H // Hk, dim=1) if Hk != H else kf
+    ve = vf.repeat_interleave(H // Hk, dim=1) if Hk != H else vf
+    s = torch.matmul(qf, ke.transpose(2, 3)) * softmax_scale
+    if is_causal:
+        i = torch.arange(Nq)[:, None]
+        j = torch.arange(Nk)[None, :]
+        s = s.masked_fill(j > i + (Nk - Nq), float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)      # rows with no visible key
+    o = torch.matmul(p, ve)
+    o.backward(dout.detach().cpu().to(dtype))
+    return qf.grad, kf.grad, vf.grad
+
+
 def abs_weighted(q, k, v, is_causal, softmax_scale):
     """A[i,d] = sum_j P[i,j] |v[j,d]| — the non-cancelling magnitude of each output element; the
     natural scale for error bounds on O (|O| <= A, with equality when no cancellation)."""

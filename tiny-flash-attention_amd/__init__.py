@@ -20,6 +20,7 @@ from .ops import (  # noqa: F401
     naive_attn,
     flash_attn_func,
     flash_attn_fwd,
+    flash_attn_bwd,
 )
 from . import _lib  # noqa: F401
 
@@ -32,4 +33,5 @@ __all__ = [
     "naive_attn",
     "flash_attn_func",
     "flash_attn_fwd",
+    "flash_attn_bwd",
 ]

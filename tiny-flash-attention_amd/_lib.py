@@ -24,6 +24,10 @@ SYMBOLS = (
     "tfa_variant_name",
     "tfa_fwd_work",
     "tfa_debug_set_trace",
+    "tfa_bwd",
+    "tfa_bwd_plan",
+    "tfa_bwd_work",
+    "tfa_bwd_time",
 )
 
 
@@ -50,6 +54,41 @@ class TfaFwdParams(C.Structure):
         ("is_causal", C.c_int32),
         ("dtype", C.c_int32),
         ("out_dtype", C.c_int32),
+    ]
+
+
+class TfaBwdParams(C.Structure):
+    """struct tfa_bwd_params (include/tfa.h)."""
+
+    _fields_ = [
+        ("q", C.c_void_p),
+        ("k", C.c_void_p),
+        ("v", C.c_void_p),
+        ("out", C.c_void_p),
+        ("dout", C.c_void_p),
+        ("lse", C.c_void_p),
+        ("dq", C.c_void_p),
+        ("dk", C.c_void_p),
+        ("dv", C.c_void_p),
+        ("delta", C.c_void_p),
+        ("B", C.c_int32),
+        ("H", C.c_int32),
+        ("Hk", C.c_int32),
+        ("Nq", C.c_int32),
+        ("Nk", C.c_int32),
+        ("D", C.c_int32),
+        ("q_stride", C.c_int64 * 3),
+        ("k_stride", C.c_int64 * 3),
+        ("v_stride", C.c_int64 * 3),
+        ("o_stride", C.c_int64 * 3),
+        ("do_stride", C.c_int64 * 3),
+        ("dq_stride", C.c_int64 * 3),
+        ("dk_stride", C.c_int64 * 3),
+        ("dv_stride", C.c_int64 * 3),
+        ("softmax_scale", C.c_float),
+        ("is_causal", C.c_int32),
+        ("dtype", C.c_int32),
+        ("grad_dtype", C.c_int32),
     ]
 
 
@@ -98,6 +137,15 @@ def lib():
     L.tfa_variant_name.argtypes = [C.c_int]
     L.tfa_debug_set_trace.restype = C.c_int
     L.tfa_debug_set_trace.argtypes = [C.c_void_p]
+    PB = C.POINTER(TfaBwdParams)
+    L.tfa_bwd.restype = C.c_int
+    L.tfa_bwd.argtypes = [PB, C.c_void_p]
+    L.tfa_bwd_plan.restype = C.c_int
+    L.tfa_bwd_plan.argtypes = [PB]
+    L.tfa_bwd_work.restype = C.c_int
+    L.tfa_bwd_work.argtypes = [PB, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.tfa_bwd_time.restype = C.c_int
+    L.tfa_bwd_time.argtypes = [PB, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
     L.tfa_fwd_work.restype = C.c_int
     L.tfa_fwd_work.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = L

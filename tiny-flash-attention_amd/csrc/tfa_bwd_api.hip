@@ -1,0 +1,161 @@
+// tfa_bwd_api.hip — extern "C" backward entry points of include/tfa.h: validate, fill kernel arguments, launch
+// delta -> dQ -> dK -> dV on the caller's stream (see tfa_bwd_kernel.h for the kernels).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "tfa.h"
+#include "tfa_bwd_launch.h"
+
+namespace tfa {
+template <> hipError_t launch_bwd<__bf16, 64>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd<__bf16, 128>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd<_Float16, 64>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd<_Float16, 128>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_delta<__bf16, 64>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, hipStream_t, bool);
+template <> hipError_t launch_delta<__bf16, 128>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, hipStream_t, bool);
+template <> hipError_t launch_delta<_Float16, 64>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, hipStream_t, bool);
+template <> hipError_t launch_delta<_Float16, 128>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, hipStream_t, bool);
+}  // namespace tfa
+
+namespace {
+
+bool slice_bytes(int64_t n, int64_t row_stride, int d, int esize, unsigned* out) {
+  const int64_t bytes = ((n - 1) * row_stride + d) * esize;
+  const int64_t reach = ((n + 512) * row_stride + d) * esize;   // every byte offset a kernel forms stays inside int32
+  if (bytes <= 0 || reach >= (int64_t)0x7fffffff) return false;
+  *out = (unsigned)bytes;
+  return true;
+}
+
+bool fill(tfa::BTensor* t, const void* ptr, const int64_t* st, int64_t n, int d, int esize) {
+  t->p = ptr;
+  t->s_b = st[0]; t->s_h = st[1]; t->s_n = st[2];
+  return slice_bytes(n, st[2], d, esize, &t->bytes);
+}
+
+int check_strides(const int64_t* st, int d, int esize) {
+  for (int i = 0; i < 3; ++i) {
+    if (st[i] < 0) return TFA_ERR_STRIDE;
+    if ((st[i] * esize) % 16 != 0) return TFA_ERR_STRIDE;
+  }
+  if (st[2] < d) return TFA_ERR_STRIDE;
+  return TFA_OK;
+}
+
+int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
+  if (!p) return TFA_ERR_NULL;
+  if (!p->q || !p->k || !p->v || !p->out || !p->dout || !p->lse || !p->dq || !p->dk || !p->dv || !p->delta) return TFA_ERR_NULL;
+  if (p->dtype != TFA_F16 && p->dtype != TFA_BF16) return TFA_ERR_DTYPE;
+  if (p->grad_dtype != p->dtype && p->grad_dtype != TFA_F32) return TFA_ERR_DTYPE;
+  if (p->D != 64 && p->D != 128) return TFA_ERR_HEAD_DIM;
+  if (p->B <= 0 || p->H <= 0 || p->Hk <= 0 || p->Nq <= 0 || p->Nk <= 0 || p->H % p->Hk != 0) return TFA_ERR_SHAPE;
+  if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
+  const int esz = 2, gsz = (p->grad_dtype == TFA_F32) ? 4 : 2;
+  const int64_t* in_st[5] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride, p->do_stride};
+  for (int i = 0; i < 5; ++i) { const int st = check_strides(in_st[i], p->D, esz); if (st) return st; }
+  const int64_t* g_st[3] = {p->dq_stride, p->dk_stride, p->dv_stride};
+  for (int i = 0; i < 3; ++i) { const int st = check_strides(g_st[i], p->D, gsz); if (st) return st; }
+  const uintptr_t al = (uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->out | (uintptr_t)p->dout | (uintptr_t)p->dq |
+                       (uintptr_t)p->dk | (uintptr_t)p->dv;
+  if (al & 15) return TFA_ERR_ALIGN;
+  if (((uintptr_t)p->lse | (uintptr_t)p->delta) & 15) return TFA_ERR_ALIGN;   // read as 16-byte vectors
+  if ((int64_t)p->B * p->H * p->Nq >= (int64_t)0x1fffffff) return TFA_ERR_SHAPE;
+
+  tfa::BArgs a;
+  memset(&a, 0, sizeof(a));
+  if (!fill(&a.q, p->q, p->q_stride, p->Nq, p->D, esz)) return TFA_ERR_STRIDE;
+  if (!fill(&a.k, p->k, p->k_stride, p->Nk, p->D, esz)) return TFA_ERR_STRIDE;
+  if (!fill(&a.v, p->v, p->v_stride, p->Nk, p->D, esz)) return TFA_ERR_STRIDE;
+  if (!fill(&a.dout, p->dout, p->do_stride, p->Nq, p->D, esz)) return TFA_ERR_STRIDE;
+  unsigned ob = 0;
+  if (!slice_bytes(p->Nq, p->o_stride[2], p->D, esz, &ob)) return TFA_ERR_STRIDE;
+  a.lse = p->lse; a.delta = p->delta;
+  a.B = p->B; a.H = p->H; a.Hk = p->Hk; a.Nq = p->Nq; a.Nk = p->Nk;
+  a.scale = p->softmax_scale;
+  a.scale_log2 = p->softmax_scale * 1.4426950408889634f;
+  const bool causal = p->is_causal != 0, f32 = p->grad_dtype == TFA_F32;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+
+  auto launch = [&](int mode, void* grad, const int64_t* gst, int n_res, int h_res) -> int {
+    tfa::BArgs m = a;
+    m.grad = grad; m.gs_b = gst[0]; m.gs_h = gst[1]; m.gs_n = gst[2];
+    if (!slice_bytes(n_res, gst[2], p->D, gsz, &m.g_bytes)) return TFA_ERR_STRIDE;
+    m.nrb = (n_res + 255) / 256;
+    const int64_t grid = (int64_t)p->B * h_res * m.nrb;
+    if (grid >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
+    hipError_t e;
+    if (p->dtype == TFA_BF16)
+      e = (p->D == 128) ? tfa::launch_bwd<__bf16, 128>(m, mode, (int)grid, causal, f32, s, dry) : tfa::launch_bwd<__bf16, 64>(m, mode, (int)grid, causal, f32, s, dry);
+    else
+      e = (p->D == 128) ? tfa::launch_bwd<_Float16, 128>(m, mode, (int)grid, causal, f32, s, dry) : tfa::launch_bwd<_Float16, 64>(m, mode, (int)grid, causal, f32, s, dry);
+    return (int)e;
+  };
+
+  // delta = rowsum(dout o out)
+  {
+    const long long os[3] = {p->o_stride[0], p->o_stride[1], p->o_stride[2]};
+    const long long ds[3] = {p->do_stride[0], p->do_stride[1], p->do_stride[2]};
+    const long long rows = (long long)p->B * p->H * p->Nq;
+    hipError_t e;
+    if (p->dtype == TFA_BF16)
+      e = (p->D == 128) ? tfa::launch_delta<__bf16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, s, dry)
+                        : tfa::launch_delta<__bf16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, s, dry);
+    else
+      e = (p->D == 128) ? tfa::launch_delta<_Float16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, s, dry)
+                        : tfa::launch_delta<_Float16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, s, dry);
+    if (e != hipSuccess) return (int)e;
+  }
+  int st = launch(tfa::BWD_DQ, p->dq, p->dq_stride, p->Nq, p->H);
+  if (st) return st;
+  st = launch(tfa::BWD_DK, p->dk, p->dk_stride, p->Nk, p->Hk);
+  if (st) return st;
+  return launch(tfa::BWD_DV, p->dv, p->dv_stride, p->Nk, p->Hk);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tfa_bwd(const tfa_bwd_params* p, void* stream) { return run_bwd(p, stream, false); }
+int tfa_bwd_plan(const tfa_bwd_params* p) { return run_bwd(p, nullptr, true); }
+
+int tfa_bwd_work(const tfa_bwd_params* p, double* flops, double* bytes) {
+  const int st = run_bwd(p, nullptr, true);
+  if (st) return st;
+  const double heads = (double)p->B * p->H, f = p->is_causal ? 0.5 : 1.0;
+  if (flops) *flops = 10.0 * heads * p->Nq * (double)p->Nk * p->D * f;
+  if (bytes) {
+    const double gsz = p->grad_dtype == TFA_F32 ? 4.0 : 2.0;
+    const double qrows = heads * p->Nq * p->D, krows = (double)p->B * p->Hk * p->Nk * p->D;
+    *bytes = 2.0 * (3.0 * qrows + 2.0 * krows) + gsz * (qrows + 2.0 * krows) + 4.0 * heads * p->Nq;
+  }
+  return TFA_OK;
+}
+
+int tfa_bwd_time(const tfa_bwd_params* p, int warmup, int iters, void* stream, float* avg_ms) {
+  if (!avg_ms || iters <= 0 || warmup < 0) return TFA_ERR_NULL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int i = 0; i < warmup; ++i) { const int st = run_bwd(p, stream, false); if (st) return st; }
+  hipEvent_t e0, e1;
+  hipError_t e = hipEventCreate(&e0);
+  if (e != hipSuccess) return (int)e;
+  e = hipEventCreate(&e1);
+  if (e != hipSuccess) { (void)hipEventDestroy(e0); return (int)e; }
+  int st = 0;
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters && st == 0; ++i) st = run_bwd(p, stream, false);
+  (void)hipEventRecord(e1, s);
+  e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (st) return st;
+  if (e != hipSuccess) return (int)e;
+  *avg_ms = ms / (float)iters;
+  return TFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,350 @@
+// tfa_bwd_kernel.h — FlashAttention-2 backward for gfx950, first correct version.
+//
+// The reference has no backward; it only saves the LSE for one ("LogSumExp save for backward",
+// flash_attention_cutlass/csrc/flash_attention.cu:353-354,614-623; tiny_flash_attn_triton.py:27-29).  The math is
+// the standard one:  P = exp(S*scale - LSE),  dV = P^T dO,  dP = dO V^T,  dS = P o (dP - delta) * scale with
+// delta_i = sum_d dO_id O_id,  dQ = dS K,  dK = dS^T Q.
+//
+// ONE kernel template, three launches (dQ, dK, dV), each a role assignment of the forward kernel's two GEMM forms, so
+// every layout below is the forward's, already verified on hardware:
+//   * a wave owns 32 RESIDENT rows (one per lane: query rows for dQ, key rows for dK/dV) whose 16-bit fragments stay in
+//     registers as MFMA B operands; the other sequence is STREAMED in 64-row tiles through LDS by LDS-DMA;
+//   * "GEMM-I"  X^T[tile row, resident row] = Tile . Resident^T  (tile image in the K layout: row-major, XOR swizzle)
+//       gives S (and dP) with the resident row in the lane and 16 tile rows per accumulator;
+//   * "GEMM-II" Acc^T[d, resident row] += Tile^T . Y  (tile image in the V layout: ds_read_b64_tr_b16) with Y = P or dS
+//       taken straight from the GEMM-I accumulator registers (16-bit pack, no data movement).
+//   dQ: resident Q, dO;  tiles K (K layout), V (K layout), K (V layout);  row statistics (LSE, delta) per lane.
+//   dK: resident K, V;   tiles Q (K layout), dO (K layout), Q (V layout); statistics per TILE row (loaded per tile).
+//   dV: resident K;      tiles Q (K layout), dO (V layout).
+// No atomics, no transposes through LDS, deterministic; the price is that S is recomputed three times and dP twice
+// (8 GEMM units instead of 5).  Burst-structured like tfa_fwd_kernel_dma.h (two LDS stages, one barrier per tile);
+// the issue-interleaving of tfa_fwd_kernel_il.h is the next step for this kernel.
+#pragma once
+#include "tfa_fwd_kernel_dma.h"
+
+namespace tfa {
+
+struct BTensor {
+  const void* p;
+  long long s_b, s_h, s_n;   // strides in elements; unit stride along D
+  unsigned bytes;            // extent of one (b,h) slice in bytes (buffer descriptor range)
+};
+
+struct BArgs {
+  BTensor q, k, v, dout;
+  void* grad;                // output of this launch: dQ, dK or dV
+  long long gs_b, gs_h, gs_n;
+  unsigned g_bytes;
+  const float* lse;          // (B,H,Nq) natural-log LSE from the forward
+  const float* delta;        // (B,H,Nq) rowsum(dO o O)
+  int B, H, Hk, Nq, Nk;
+  int nrb;                   // 256-row resident blocks per (b, resident head)
+  float scale, scale_log2;
+};
+
+enum { BWD_DQ = 0, BWD_DK = 1, BWD_DV = 2 };
+
+template <typename T, int D, int MODE, bool CAUSAL, bool F32OUT>
+__global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
+  using E = Elem<T>;
+  using X8 = typename E::x8;
+  constexpr int NW = 8;
+  constexpr int BM = NW * 32;                      // resident rows per workgroup
+  constexpr int BN = 64;                           // streamed rows per tile
+  constexpr int CPR = D / 8;
+  constexpr int TILE_BYTES = BN * D * 2;
+  constexpr int PIECES = TILE_BYTES / 1024;
+  constexpr int PPW = PIECES / NW;
+  constexpr int DS = D / 16;
+  constexpr int DT = D / 32;
+  constexpr bool KEYS_RES = MODE != BWD_DQ;        // resident rows are keys
+  constexpr bool NEED_DP = MODE != BWD_DV;
+  constexpr int NIMG = MODE == BWD_DV ? 2 : 3;     // LDS images per tile
+  constexpr int IMG_TR = NIMG - 1;                 // the image in the V (transpose-read) layout
+  static_assert(PPW >= 1 && PPW * NW == PIECES, "");
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 31;
+  const int hi = lane >> 5;
+
+  const int G = p.H / p.Hk;
+  const int Hres = KEYS_RES ? p.Hk : p.H;
+  const int rb = blockIdx.x % p.nrb;
+  const int bhr = blockIdx.x / p.nrb;
+  const int b = bhr / Hres;
+  const int hr = bhr - b * Hres;
+  const int shift = p.Nk - p.Nq;
+  const int r0 = rb * BM;
+  const int wave_row0 = r0 + wave * 32;
+  const int my_row = wave_row0 + qi;
+  const int NG = KEYS_RES ? G : 1;                 // streamed heads per resident head
+
+  // ---- streamed tile range of this block -----------------------------------------------------------------------
+  int t_begin = 0, t_end;
+  if (!KEYS_RES) {
+    int kv_end = p.Nk;
+    if (CAUSAL) {
+      const int lim = r0 + BM + shift;
+      kv_end = lim < kv_end ? lim : kv_end;
+    }
+    t_end = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+  } else {
+    t_end = (p.Nq + BN - 1) / BN;
+    if (CAUSAL) {
+      const int qmin = r0 - shift;                 // first query row that sees key r0
+      t_begin = qmin > 0 ? qmin / BN : 0;
+      if (t_begin > t_end) t_begin = t_end;
+    }
+  }
+  const int ntl = t_end - t_begin;                 // tiles per streamed head
+  const int nu = ntl * NG;                         // tiles of the whole flat sequence (head-major)
+
+  // ---- per-lane DMA source offsets (bytes) of the images, relative to the streamed (b,h) slice -------------------
+  // image tensors: dQ: K, V, K   dK: Q, dO, Q   dV: Q, dO
+  auto img_tensor = [&](int img) -> const BTensor& {
+    if (MODE == BWD_DQ) return img == 1 ? p.v : p.k;
+    return img == 1 ? p.dout : p.q;
+  };
+  int src[NIMG][PPW];
+  int tile_stride[NIMG];
+#pragma unroll
+  for (int img = 0; img < NIMG; ++img) {
+    const int sn = (int)img_tensor(img).s_n;
+    tile_stride[img] = BN * sn * 2;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;
+      if (img != IMG_TR) {                           // K layout
+        const int row = pc * (1024 / (D * 2)) + lane / CPR;
+        const int cpos = lane % CPR;
+        src[img][i] = row * sn * 2 + ((cpos ^ k_swz<D>(row)) << 4);
+      } else {                                       // V layout
+        const int o = pc * 1024 + lane * 16;
+        const int sub = o >> 9, R = (o >> 6) & 7, pcs = (o >> 4) & 3;
+        const int dt = sub % DT, sh = sub / DT;
+        const int row = 16 * (sh >> 1) + 4 * (sh & 1) + 8 * (R >> 2) + (R & 3);
+        src[img][i] = row * sn * 2 + ((dt * 4 + pcs) << 4);
+      }
+    }
+  }
+  // flat tile u -> (streamed head, tile index); the descriptors are rebuilt per call (a few SALU instructions)
+  auto dma_issue = [&](int u, int stage) {
+    const int g = u / ntl;
+    const int jt = t_begin + (u - g * ntl);
+    const int hs = KEYS_RES ? (hr * G + g) : (hr / G);
+#pragma unroll
+    for (int img = 0; img < NIMG; ++img) {
+      const BTensor& x = img_tensor(img);
+      const T* base = reinterpret_cast<const T*>(x.p) + b * x.s_b + hs * x.s_h;
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < PPW; ++i)
+        lds_dma16(rs, lds_base + (stage * NIMG + img) * TILE_BYTES + (wave * PPW + i) * 1024, src[img][i] + jt * tile_stride[img]);
+    }
+  };
+
+  // ---- resident fragments and per-lane statistics -----------------------------------------------------------------
+  X8 r1f[DS], r2f[NEED_DP ? DS : 1];
+  {
+    const BTensor& x1 = KEYS_RES ? p.k : p.q;
+    const T* b1 = reinterpret_cast<const T*>(x1.p) + b * x1.s_b + hr * x1.s_h;
+    auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, x1.bytes, 0x00020000);
+    const int off1 = my_row * (int)x1.s_n * 2 + hi * 16;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) r1f[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs1, off1 + s * 32, 0, 0));
+    if (NEED_DP) {
+      const BTensor& x2 = KEYS_RES ? p.v : p.dout;
+      const T* b2 = reinterpret_cast<const T*>(x2.p) + b * x2.s_b + hr * x2.s_h;
+      auto rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)b2, 0, x2.bytes, 0x00020000);
+      const int off2 = my_row * (int)x2.s_n * 2 + hi * 16;
+#pragma unroll
+      for (int s = 0; s < DS; ++s) r2f[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs2, off2 + s * 32, 0, 0));
+    }
+  }
+  float lse2_lane = 0.f, delta_lane = 0.f;           // dQ: statistics of the lane's own query row
+  if (!KEYS_RES && my_row < p.Nq) {
+    const long long si = (long long)(b * p.H + hr) * p.Nq + my_row;
+    lse2_lane = p.lse[si] * 1.4426950408889634f;
+    delta_lane = p.delta[si];
+  }
+
+  f32x16 acc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+  const int k_rd_base = qi * (D * 2);
+  const int k_rd_swz = k_swz<D>(qi);
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
+  const float sc = p.scale_log2;
+
+  if (nu > 0) dma_issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(r1f[s]));
+  if (NEED_DP) {
+#pragma unroll
+    for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(r2f[s]));
+  }
+  asm volatile("s_barrier" ::: "memory");
+
+#pragma nounroll
+  for (int u = 0; u < nu; ++u) {
+    const int stage = u & 1;
+    if (u + 1 < nu) dma_issue(u + 1, stage ^ 1);     // the other stage was released by the barrier that ended tile u-1
+    const int g = u / ntl;
+    const int jt = t_begin + (u - g * ntl);
+    const int row0 = jt * BN;                        // first streamed row of the tile (a key for dQ, a query for dK/dV)
+    const char* img0 = smem + (stage * NIMG + 0) * TILE_BYTES;
+    const char* img1 = smem + (stage * NIMG + 1) * TILE_BYTES;
+    const char* imgt = smem + (stage * NIMG + IMG_TR) * TILE_BYTES;
+
+    // does any element of this wave's 32 x 64 piece need masking?
+    bool need_mask;
+    if (!KEYS_RES) {
+      need_mask = (row0 + BN > p.Nk);
+      if (CAUSAL) need_mask = need_mask || (row0 + BN - 1 > wave_row0 + shift);
+    } else {
+      need_mask = CAUSAL && (row0 < wave_row0 + 31 - shift);
+    }
+    // per tile-row statistics (dK/dV): descriptor over the (b, h) row of the (B,H,Nq) arrays, OOB -> 0
+    __amdgpu_buffer_rsrc_t lse_rs, dl_rs;
+    if (KEYS_RES) {
+      const long long so = (long long)(b * p.H + hr * G + g) * p.Nq;
+      lse_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + so), 0, (unsigned)p.Nq * 4u, 0x00020000);
+      dl_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.delta + so), 0, (unsigned)p.Nq * 4u, 0x00020000);
+    }
+
+    X8 pk[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      // ---- GEMM-I: S (and dP) for the 32 tile rows of half t ----------------------------------------------------
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int sl = 0; sl < DS; ++sl) {
+        const int off = k_rd_base + t * 32 * (D * 2) + (((2 * sl + hi) ^ k_rd_swz) << 4);
+        s = E::mfma(__builtin_bit_cast(X8, lds_read_b128(img0, off)), r1f[sl], s);
+        if (NEED_DP) dp = E::mfma(__builtin_bit_cast(X8, lds_read_b128(img1, off)), r2f[sl], dp);
+      }
+      // ---- statistics of the 16 tile rows this lane sees (dK/dV) --------------------------------------------------
+      float lse2[16], dl[16];
+      if (KEYS_RES) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int q = row0 + 32 * t + 8 * g4 + 4 * hi;
+          const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lse_rs, q * 4, 0, 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lse2[4 * g4 + e] = a[e] * 1.4426950408889634f;
+          if (NEED_DP) {
+            const f32x4 c = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dl_rs, q * 4, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dl[4 * g4 + e] = c[e];
+          }
+        }
+      }
+      // ---- mask ---------------------------------------------------------------------------------------------------
+      if (need_mask) {
+        if (!KEYS_RES) {
+          int lim = p.Nk - 1;
+          if (CAUSAL) { const int c = my_row + shift; lim = c < lim ? c : lim; }
+          lim -= row0 + 4 * hi;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ko = 32 * t + (r & 3) + 8 * (r >> 2);
+            if (ko > lim) s[r] = -INFINITY;
+          }
+        } else {
+          const int limq = my_row - shift - row0 - 4 * hi;     // query offsets below this do not see the lane's key
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qo = 32 * t + (r & 3) + 8 * (r >> 2);
+            if (qo < limq) s[r] = -INFINITY;
+          }
+        }
+      }
+      // ---- P, dS, 16-bit pack ---------------------------------------------------------------------------------------
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float l2 = KEYS_RES ? lse2[r] : lse2_lane;
+        const float pr = fast_exp2(fmaf(s[r], sc, -l2));
+        float y = pr;
+        if (NEED_DP) y = pr * (dp[r] - (KEYS_RES ? dl[r] : delta_lane));
+        pk[t * 2 + (r >> 3)][r & 7] = (T)y;
+      }
+      // ---- GEMM-II for the two 16-row slots of this half -----------------------------------------------------------
+#pragma unroll
+      for (int sl = 2 * t; sl < 2 * t + 2; ++sl)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const char* a = imgt + v_rd_base + (sl * 2 * DT << 9) + (d << 9);
+          s16x4 lo = lds_read_tr16_b64(a);
+          s16x4 hh = lds_read_tr16_b64(a + 256);
+          s16x8 vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[d] = E::mfma(__builtin_bit_cast(X8, vf), pk[sl], acc[d]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
+  // ---- epilogue: acc[dt][r] = grad[row my_row][32*dt + (r&3) + 8*(r>>2) + 4*hi] ----------------------------------------
+  const float osc = (MODE == BWD_DV) ? 1.f : p.scale;
+  if (F32OUT) {
+    float* gb = reinterpret_cast<float*>(p.grad) + b * p.gs_b + hr * p.gs_h;
+    auto g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, p.g_bytes, 0x00020000);
+    const int goff = my_row * (int)p.gs_n * 4 + hi * 16;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 v4 = {acc[d][4 * g4 + 0] * osc, acc[d][4 * g4 + 1] * osc, acc[d][4 * g4 + 2] * osc, acc[d][4 * g4 + 3] * osc};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), g_rs, goff + (d * 32 + g4 * 8) * 4, 0, 0);
+      }
+  } else {
+    T* gb = reinterpret_cast<T*>(p.grad) + b * p.gs_b + hr * p.gs_h;
+    auto g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, p.g_bytes, 0x00020000);
+    const int goff = my_row * (int)p.gs_n * 2 + hi * 8;
+    typedef __attribute__((ext_vector_type(4))) T t4;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        t4 v4 = {(T)(acc[d][4 * g4 + 0] * osc), (T)(acc[d][4 * g4 + 1] * osc), (T)(acc[d][4 * g4 + 2] * osc), (T)(acc[d][4 * g4 + 3] * osc)};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), g_rs, goff + (d * 32 + g4 * 8) * 2, 0, 0);
+      }
+  }
+}
+
+// delta[b,h,i] = sum_d dO[b,h,i,d] * O[b,h,i,d]  (fp32).  LPR lanes per row, 8 elements (16 bytes) per lane.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void bwd_delta_kernel(const void* o, const void* dout, float* delta, long long os_b, long long os_h, long long os_n,
+                                                       long long ds_b, long long ds_h, long long ds_n, int H, int Nq, long long rows) {
+  constexpr int LPR = D / 8;
+  typedef __attribute__((ext_vector_type(8))) T t8;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long row = gid / LPR;
+  const int c = (int)(gid % LPR);
+  float acc = 0.f;
+  if (row < rows) {
+    const long long bh = row / Nq;
+    const int i = (int)(row - bh * Nq);
+    const int b = (int)(bh / H), h = (int)(bh - (long long)b * H);
+    const t8 a = *reinterpret_cast<const t8*>(reinterpret_cast<const T*>(o) + b * os_b + h * os_h + i * os_n + c * 8);
+    const t8 g = *reinterpret_cast<const t8*>(reinterpret_cast<const T*>(dout) + b * ds_b + h * ds_h + i * ds_n + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)g[e];
+  }
+#pragma unroll
+  for (int m = LPR / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if (row < rows && c == 0) delta[row] = acc;
+}
+
+}  // namespace tfa

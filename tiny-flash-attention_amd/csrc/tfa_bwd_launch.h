@@ -1,0 +1,12 @@
+// tfa_bwd_launch.h — host-side declarations shared by the backward instantiation units and tfa_bwd_api.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tfa_bwd_kernel.h"
+
+namespace tfa {
+template <typename T, int D>
+hipError_t launch_bwd(const BArgs& a, int mode, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);
+template <typename T, int D>
+hipError_t launch_delta(const void* o, const void* dout, float* delta, const long long* os, const long long* ds, int H, int Nq, long long rows,
+                        hipStream_t stream, bool dry);
+}  // namespace tfa

@@ -105,6 +105,61 @@ def make_params(q, k, v, out, lse, is_causal, softmax_scale, layout="bhnd"):
     return p
 
 
+def make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, is_causal, softmax_scale, layout="bhnd"):
+    """Build a TfaBwdParams for existing buffers."""
+    p = _lib.TfaBwdParams()
+    p.q, p.k, p.v, p.out, p.dout = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr()
+    p.lse, p.delta = lse.data_ptr(), delta.data_ptr()
+    p.dq, p.dk, p.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    if layout == "bhnd":
+        B, H, Nq, D = q.shape
+        _, Hk, Nk, _ = k.shape
+    else:
+        B, Nq, H, D = q.shape
+        _, Nk, Hk, _ = k.shape
+    p.B, p.H, p.Hk, p.Nq, p.Nk, p.D = B, H, Hk, Nq, Nk, D
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", out), ("do_stride", dout),
+                    ("dq_stride", dq), ("dk_stride", dk), ("dv_stride", dv)):
+        s = _strides_bhnd(t, layout)
+        arr = getattr(p, name)
+        arr[0], arr[1], arr[2] = s
+    p.softmax_scale = float(softmax_scale)
+    p.is_causal = 1 if is_causal else 0
+    p.dtype = _DT[q.dtype]
+    p.grad_dtype = _lib.TFA_F32 if dq.dtype == torch.float32 else _DT[dq.dtype]
+    return p
+
+
+def flash_attn_bwd(q, k, v, out, lse, dout, is_causal=False, softmax_scale=None, *, layout="bhnd", grad_f32=False):
+    """Backward of ``flash_attn_fwd``: returns ``(dq, dk, dv)`` shaped like q, k, v (fp32 when ``grad_f32``).
+    ``out`` and ``lse`` are the forward's results for the same q, k, v; ``dout`` is the upstream gradient
+    (shape/dtype of ``out``).  The reference has no backward — it only saves the LSE for one
+    (flash_attention_cutlass/csrc/flash_attention.cu:353-354,614-623); maps onto tfa_bwd (include/tfa.h)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
+        if not t.is_cuda:
+            raise RuntimeError(f"{n} must be a CUDA tensor")
+        if t.dim() != 4 or t.stride(3) != 1:
+            raise RuntimeError(f"{n} must be 4-D with unit stride along the head dimension")
+    if q.dtype not in _DT or any(t.dtype != q.dtype for t in (k, v, out, dout)):
+        raise TypeError("q,k,v,out,dout must share dtype float16 or bfloat16")
+    if out.shape != q.shape or dout.shape != q.shape or k.shape != v.shape:
+        raise RuntimeError("shape mismatch")
+    D = q.shape[-1]
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(D)
+    lse = lse.contiguous()
+    gdt = torch.float32 if grad_f32 else q.dtype
+    dq = torch.empty(q.shape, dtype=gdt, device=q.device)
+    dk = torch.empty(k.shape, dtype=gdt, device=q.device)
+    dv = torch.empty(v.shape, dtype=gdt, device=q.device)
+    delta = torch.empty(lse.shape, dtype=torch.float32, device=q.device)
+    p = make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, is_causal, softmax_scale, layout)
+    with torch.cuda.device(q.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().tfa_bwd(C.byref(p), C.c_void_p(stream)))
+    return dq, dk, dv
+
+
 # ---------------------------------------------------------------------------------------------
 # the reference's three operator entry points
 # ---------------------------------------------------------------------------------------------
