@@ -252,6 +252,37 @@ def attn_bwd_reference(q, k, v, dout, is_causal, softmax_scale, dtype=torch.floa
     return qf.grad, kf.grad, vf.grad
 
 
+def attn_bwd_bounds(q, k, v, out, dout, is_causal, softmax_scale):
+    """Non-cancelling magnitudes of the three gradients, for error bounds like ``abs_weighted`` gives for O:
+    rounding P (for dV) and dS (for dQ, dK) to 16 bit perturbs each term of the sums by a relative 2^-9 (bf16)
+    / 2^-12 (fp16), and delta_i = sum_d dO_id O_id is formed from the 16-bit O the forward stored, which
+    moves every dS_ij by P_ij * 2^-9 * sum_d |dO_id O_id| (inherent to the algorithm: it re-uses the saved O).
+    Returns (Aq, Ak, Av) in fp64, shaped like q, k, v:  |grad_kernel - grad_exact| <= eps16 * A (+ final rounding)."""
+    qf, kf, vf = (t.detach().cpu().double() for t in (q, k, v))
+    of, dof = out.detach().cpu().double(), dout.detach().cpu().double()
+    B, H, Nq, D = qf.shape
+    Hk, Nk = kf.shape[1], kf.shape[2]
+    G = H // Hk
+    ke = kf.repeat_interleave(G, dim=1) if G > 1 else kf
+    ve = vf.repeat_interleave(G, dim=1) if G > 1 else vf
+    s = torch.matmul(qf, ke.transpose(2, 3)) * softmax_scale
+    if is_causal:
+        i = torch.arange(Nq)[:, None]
+        j = torch.arange(Nk)[None, :]
+        s = s.masked_fill(j > i + (Nk - Nq), float("-inf"))
+    p = torch.nan_to_num(torch.softmax(s, dim=-1), nan=0.0)
+    dp = torch.matmul(dof, ve.transpose(2, 3))
+    delta = (dof * of).sum(-1, keepdim=True)
+    ds_abs = p * ((dp - delta).abs() + (dof * of).abs().sum(-1, keepdim=True))   # |dS| + its sensitivity to the rounded O
+    aq = softmax_scale * torch.matmul(ds_abs, ke.abs())
+    ak = softmax_scale * torch.matmul(ds_abs.transpose(2, 3), qf.abs())
+    av = torch.matmul(p.transpose(2, 3), dof.abs())
+    if G > 1:
+        ak = ak.view(B, Hk, G, Nk, D).sum(2)
+        av = av.view(B, Hk, G, Nk, D).sum(2)
+    return aq, ak, av
+
+
 def abs_weighted(q, k, v, is_causal, softmax_scale):
     """A[i,d] = sum_j P[i,j] |v[j,d]| — the non-cancelling magnitude of each output element; the
     natural scale for error bounds on O (|O| <= A, with equality when no cancellation)."""

@@ -1,0 +1,155 @@
+"""GPU parity tests of the backward pass (tfa_bwd through the C ABI) against the fp64 autograd oracle.
+
+The reference has no backward (it only saves the LSE for one, flash_attention.cu:353-354,614-623), so the
+oracle is the function the reference's forward implements (attn.cpp:35-98), differentiated by autograd in fp64
+on identical seeded inputs (oracle.attn_bwd_reference).  Tolerances (floating point):
+  (B1) fp32-gradient debug path: |d| <= eps16 * A + 1e-6 with eps16 = 2^-8 (bf16) / 2^-11 (fp16) and
+       A = oracle.attn_bwd_bounds: the non-cancelling magnitude of each gradient element, i.e. the rigorous
+       bound for rounding P and dS to 16 bit (what FlashAttention-2 does) and for forming delta from the
+       16-bit O the forward stored.
+  (B2) 16-bit gradients: (B1) plus half an ulp of the result.
+  (B3) against the reference's own bar for its forward (atol 1e-2, test.py:87), scaled with the gradient
+       magnitude: max|d| <= 1e-2 * max(1, max|ref|).
+"""
+import math
+
+import pytest
+import torch
+
+from helpers import ulp16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def tfa():
+    import tiny_flash_attention_amd as m
+    from tiny_flash_attention_amd import _lib
+
+    _lib.lib()
+    return m
+
+
+def make_dout(B, H, Nq, D, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.empty((B, H, Nq, D), dtype=torch.float32).normal_(0.0, 0.5, generator=g).to(dtype)
+
+
+def check_grads(oracle, grads32, grads16, q, k, v, out16, dout, causal, sc, dtype):
+    ref = oracle.attn_bwd_reference(q, k, v, dout, causal, sc)
+    bounds = oracle.attn_bwd_bounds(q, k, v, out16, dout, causal, sc)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for name, g32, g16, r, A in zip(("dq", "dk", "dv"), grads32, grads16, ref, bounds):
+        g32c, g16c = g32.double().cpu(), g16.double().cpu()
+        assert bool(torch.isfinite(g16c).all()), f"{name}: non-finite"
+        ex = ((g32c - r).abs() - (eps * A + 1e-6)).max().item()
+        assert ex <= 0, f"(B1) {name}: fp32 gradient exceeds the 16-bit rounding bound by {ex:.3e}"
+        ex16 = ((g16c - r).abs() - (eps * A + 0.5 * ulp16(r.float(), dtype).double() * (1 + 1e-3) + 1e-6)).max().item()
+        assert ex16 <= 0, f"(B2) {name}: 16-bit gradient exceeds bound + half an ulp by {ex16:.3e}"
+        assert (g16c - r).abs().max().item() <= 1e-2 * max(1.0, r.abs().max().item()), f"(B3) {name}"
+
+
+def run_bwd_case(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, seed=0, scale=None, layout="bhnd"):
+    from tiny_flash_attention_amd import ops
+
+    q, k, v = oracle.make_inputs(B, H, Nq, D, dtype, seed=seed, Hk=Hk, Nk=Nk)
+    dout = make_dout(B, H, Nq, D, dtype, seed + 100)
+    sc = 1.0 / math.sqrt(D) if scale is None else scale
+    qd, kd, vd, dod = q.to(dev), k.to(dev), v.to(dev), dout.to(dev)
+    if layout == "bnhd":
+        qd, kd, vd, dod = (t.transpose(1, 2).contiguous() for t in (qd, kd, vd, dod))
+    out, lse = ops.flash_attn_fwd(qd, kd, vd, causal, sc, layout=layout)
+    g32 = ops.flash_attn_bwd(qd, kd, vd, out, lse, dod, causal, sc, layout=layout, grad_f32=True)
+    g16 = ops.flash_attn_bwd(qd, kd, vd, out, lse, dod, causal, sc, layout=layout)
+    torch.cuda.synchronize()
+    if layout == "bnhd":
+        g32 = tuple(t.transpose(1, 2) for t in g32)
+        g16 = tuple(t.transpose(1, 2) for t in g16)
+        out = out.transpose(1, 2)
+    check_grads(oracle, g32, g16, q, k, v, out.cpu(), dout, causal, sc, dtype)
+    return g16
+
+
+BWD_SHAPES = [
+    # dtype, B, H, Hk, Nq, Nk, D, causal
+    (torch.bfloat16, 1, 2, 2, 256, 256, 128, False),
+    (torch.bfloat16, 1, 2, 2, 256, 256, 128, True),
+    (torch.float16, 2, 4, 2, 320, 320, 64, True),        # GQA, N not a multiple of the resident block
+    (torch.bfloat16, 1, 4, 1, 200, 333, 128, True),      # MQA, ragged, Nq < Nk (bottom-right causal)
+    (torch.float16, 1, 2, 2, 333, 200, 64, False),       # Nq > Nk
+    (torch.float16, 1, 3, 3, 700, 100, 128, True),       # causal with 600 query rows that see no key
+    (torch.bfloat16, 2, 2, 2, 1024, 1024, 128, True),
+    (torch.bfloat16, 1, 1, 1, 64, 64, 128, False),       # a single tile
+    (torch.float16, 1, 2, 1, 1, 500, 64, True),          # single query row (decode-like)
+    (torch.bfloat16, 1, 1, 1, 77, 65, 64, False),
+    (torch.bfloat16, 3, 2, 2, 513, 513, 64, True),
+]
+
+
+@pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D,causal", BWD_SHAPES)
+def test_bwd_parity(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal):
+    run_bwd_case(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, seed=3)
+
+
+def test_bwd_strided_bnhd_matches_bhnd(tfa, oracle, dev):
+    a = run_bwd_case(tfa, oracle, dev, torch.bfloat16, 2, 8, 2, 384, 384, 128, True, seed=5, scale=0.09)
+    b = run_bwd_case(tfa, oracle, dev, torch.bfloat16, 2, 8, 2, 384, 384, 128, True, seed=5, scale=0.09, layout="bnhd")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_bwd_deterministic_and_inputs_untouched(tfa, oracle, dev):
+    from tiny_flash_attention_amd import ops
+
+    q, k, v = (t.to(dev) for t in oracle.make_inputs(2, 4, 512, 128, torch.bfloat16, seed=9))
+    dout = make_dout(2, 4, 512, 128, torch.bfloat16, 19).to(dev)
+    keep = [t.clone() for t in (q, k, v, dout)]
+    out, lse = ops.flash_attn_fwd(q, k, v, True, 0.088)
+    g1 = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, 0.088)
+    g2 = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, 0.088)
+    torch.cuda.synchronize()
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)                      # no atomics: bit-reproducible
+    for a, b in zip((q, k, v, dout), keep):
+        assert torch.equal(a, b)
+
+
+def test_bwd_autograd_function_bnhd(tfa, oracle, dev):
+    # flash_attn_func is differentiable like the official function the reference compares against (test.py:71-76)
+    q, k, v = oracle.make_inputs(2, 4, 300, 64, torch.float16, seed=4, Hk=2)
+    qt, kt, vt = (t.transpose(1, 2).contiguous().to(dev).requires_grad_(True) for t in (q, k, v))   # (B,N,H,D)
+    out = tfa.flash_attn_func(qt, kt, vt, causal=True)
+    dout = make_dout(2, 4, 300, 64, torch.float16, 14)
+    out.backward(dout.transpose(1, 2).contiguous().to(dev))
+    ref = oracle.attn_bwd_reference(q, k, v, dout, True, 1.0 / 8.0)
+    for g, r in zip((qt.grad, kt.grad, vt.grad), ref):
+        assert (g.transpose(1, 2).double().cpu() - r).abs().max().item() <= 1e-2 * max(1.0, r.abs().max().item())
+
+
+def test_bwd_headline_shape_properties(tfa, dev):
+    """BASELINE config 3 at full size (B4 H32 N4096 D128 bf16 causal): finite, and head independence —
+    permuting heads permutes every gradient bit-exactly; dV of row-constant dO equals column sums of P."""
+    from tiny_flash_attention_amd import ops
+
+    g = torch.Generator(device=dev).manual_seed(0)
+    mk = lambda: torch.empty((2, 32, 4096, 128), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(torch.bfloat16)
+    q, k, v, dout = mk(), mk(), mk(), mk()
+    sc = 1.0 / math.sqrt(128)
+    out, lse = ops.flash_attn_fwd(q, k, v, True, sc)
+    dq, dk, dv = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, sc)
+    assert all(bool(torch.isfinite(t.float()).all()) for t in (dq, dk, dv))
+    perm = torch.randperm(32, device=dev)
+    qp, kp, vp, dp = (t[:, perm].contiguous() for t in (q, k, v, dout))
+    outp, lsep = ops.flash_attn_fwd(qp, kp, vp, True, sc)
+    dqp, dkp, dvp = ops.flash_attn_bwd(qp, kp, vp, outp, lsep, dp, True, sc)
+    assert torch.equal(dqp, dq[:, perm]) and torch.equal(dkp, dk[:, perm]) and torch.equal(dvp, dv[:, perm])
+    # sum_i dQ_i . q_i == sum_j dK_j . k_j  (both equal sum_ij dS_ij S_ij / scale ... the scale-homogeneity identity)
+    lhs = (dq.float() * q.float()).sum(dim=(2, 3))
+    rhs = (dk.float() * k.float()).sum(dim=(2, 3))
+    assert (lhs - rhs).abs().max().item() <= 2e-2 * max(1.0, lhs.abs().max().item())

@@ -74,8 +74,22 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
 
   const int G = p.H / p.Hk;
   const int Hres = KEYS_RES ? p.Hk : p.H;
-  const int rb = blockIdx.x % p.nrb;
-  const int bhr = blockIdx.x / p.nrb;
+  // Workgroups are dispatched in order and round-robin over the 8 XCDs: keep a (b, head) on one XCD (its streamed
+  // tensors are re-read by every resident block: L2 reuse) and hand out the blocks with the MOST tiles first
+  // (causal dQ: the last query block; causal dK/dV: the first key block), so the tail of the launch is short.
+  int rb, bhr;
+  {
+    const int nbh = p.B * Hres, id = blockIdx.x;
+    if ((nbh & 7) == 0) {
+      const int x = id & 7, q8 = id >> 3;
+      bhr = x + 8 * (q8 / p.nrb);
+      rb = q8 % p.nrb;
+    } else {
+      bhr = id / p.nrb;
+      rb = id % p.nrb;
+    }
+    if (CAUSAL && !KEYS_RES) rb = p.nrb - 1 - rb;
+  }
   const int b = bhr / Hres;
   const int hr = bhr - b * Hres;
   const int shift = p.Nk - p.Nq;
@@ -206,13 +220,18 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
     const char* img1 = smem + (stage * NIMG + 1) * TILE_BYTES;
     const char* imgt = smem + (stage * NIMG + IMG_TR) * TILE_BYTES;
 
-    // does any element of this wave's 32 x 64 piece need masking?
-    bool need_mask;
+    // does any element of this wave's 32 x 64 piece need masking?  is all of it masked (then the wave only keeps
+    // the DMA and the barrier going)?
+    bool need_mask, active = true;
     if (!KEYS_RES) {
       need_mask = (row0 + BN > p.Nk);
-      if (CAUSAL) need_mask = need_mask || (row0 + BN - 1 > wave_row0 + shift);
+      if (CAUSAL) {
+        need_mask = need_mask || (row0 + BN - 1 > wave_row0 + shift);
+        active = row0 <= wave_row0 + 31 + shift;
+      }
     } else {
       need_mask = CAUSAL && (row0 < wave_row0 + 31 - shift);
+      if (CAUSAL) active = row0 + BN - 1 >= wave_row0 - shift;
     }
     // per tile-row statistics (dK/dV): descriptor over the (b, h) row of the (B,H,Nq) arrays, OOB -> 0
     __amdgpu_buffer_rsrc_t lse_rs, dl_rs;
@@ -223,6 +242,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
     }
 
     X8 pk[4];
+    if (active) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       // ---- GEMM-I: S (and dP) for the 32 tile rows of half t ----------------------------------------------------
@@ -291,6 +311,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
           s16x8 vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
           acc[d] = E::mfma(__builtin_bit_cast(X8, vf), pk[sl], acc[d]);
         }
+    }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }

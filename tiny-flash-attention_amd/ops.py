@@ -206,9 +206,31 @@ def flash_attn(q, k, v, is_causal, softmax_scale):
 naive_attn = flash_attn
 
 
+class _FlashAttnBNHD(torch.autograd.Function):
+    """autograd glue for ``flash_attn_func``: forward = tfa_fwd, backward = tfa_bwd, both on (B,N,H,D) views."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, causal, softmax_scale):
+        out, lse = flash_attn_fwd(q, k, v, causal, softmax_scale, layout="bnhd")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.causal, ctx.scale = causal, softmax_scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        if dout.stride(3) != 1:
+            dout = dout.contiguous()
+        dq, dk, dv = flash_attn_bwd(q, k, v, out, lse, dout, ctx.causal, ctx.scale, layout="bnhd")
+        return dq, dk, dv, None, None
+
+
 def flash_attn_func(q, k, v, causal=False, softmax_scale=None):
     """(B,N,H,D)-layout entry with the signature the reference's scripts use for comparison
     (flash_attention_cutlass/test.py:71-76, flash_attention_py/main_torch_only.py:304);
-    supports GQA/MQA (fewer K/V heads)."""
+    supports GQA/MQA (fewer K/V heads).  Differentiable (like the official function the reference
+    compares against): when an input requires grad the backward runs tfa_bwd."""
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        return _FlashAttnBNHD.apply(q, k, v, bool(causal), softmax_scale)
     out, _ = flash_attn_fwd(q, k, v, causal, softmax_scale, layout="bnhd", return_lse=False)
     return out

@@ -1,0 +1,38 @@
+"""Backward timing on the BASELINE shapes: tfa_bwd_time (delta + dQ + dK + dV kernels per call).
+TFLOP/s uses the conventional 2.5 x forward flops (5 GEMMs); the kernels execute 8 GEMM units (S three times, dP twice).
+usage: python tools/bench_bwd.py [--cfgs cfg3,cfg3nc,cfg4] [--iters 20]"""
+import argparse, ctypes as C, math, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tiny_flash_attention_amd import _lib, ops
+CFG = {"cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096, 128, torch.bfloat16, False),
+       "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg2": (4, 8, 1024, 64, torch.float16, False),
+       "cfg5": (8, 32, 4096, 128, torch.bfloat16, True)}
+ap = argparse.ArgumentParser()
+ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4,cfg2")
+ap.add_argument("--iters", type=int, default=20)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+for cfg in a.cfgs.split(","):
+    B, H, N, D, dt, causal = CFG[cfg]
+    mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(dt)
+    q, k, v, dout = mk(), mk(), mk(), mk()
+    sc = 1 / math.sqrt(D)
+    out, lse = ops.flash_attn_fwd(q, k, v, causal, sc)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty_like(lse)
+    p = ops.make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, causal, sc)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fl, by = C.c_double(), C.c_double()
+    _lib.check(_lib.lib().tfa_bwd_work(C.byref(p), C.byref(fl), C.byref(by)))
+    best = 1e9
+    for r in range(3):
+        ms = C.c_float()
+        _lib.check(_lib.lib().tfa_bwd_time(C.byref(p), 3, a.iters, s, C.byref(ms)))
+        best = min(best, ms.value)
+    pf = ops.make_params(q, k, v, out, lse, causal, sc)
+    msf = C.c_float()
+    _lib.check(_lib.lib().tfa_fwd_time(C.byref(pf), 3, a.iters, s, C.byref(msf)))
+    print(f"{cfg:7s} bwd {best:7.3f} ms = {fl.value / best / 1e9:7.1f} TFLOP/s (2.5x-fwd convention; {fl.value / best / 1e9 * 1.6:7.1f} executed) "
+          f"| fwd {msf.value:6.3f} ms | bwd/fwd = {best / msf.value:.2f} | algorithmic {by.value / 1e6:.0f} MB")
