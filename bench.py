@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (-1 = library default)")
     ap.add_argument("--gather", action="store_true", help="also all-gather the output shards over RCCL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "bwd"],
+                    help="fwd (default, the BASELINE metric) or bwd: a step is one tfa_bwd call (delta + dQ + dK + dV kernels)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,8 +126,19 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = C.c_void_p(stream.cuda_stream)
     pref = C.byref(p)
+    bwd = args.mode == "bwd"
+    if bwd:
+        _lib.check(L.tfa_fwd(pref, sptr))                      # out, lse of this q,k,v
+        dout = mk()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        pb = ops.make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, causal, sc)
+        pbref = C.byref(pb)
 
     def step():
+        if bwd:
+            _lib.check(L.tfa_bwd(pbref, sptr))
+            return
         _lib.check(L.tfa_fwd(pref, sptr))
         if gathered is not None:
             dist.all_gather_into_tensor(gathered, out)
@@ -158,7 +171,7 @@ def main():
     # sustained shader clock: one more launch with the per-workgroup trace on (s_memtime cycles over s_memrealtime
     # 100 MHz ticks of every workgroup's life), right behind the timed region so the clock is the steady-state one
     clk_mhz = None
-    if rank == 0:
+    if rank == 0 and not bwd:
         try:
             g_, b_, l_ = C.c_int(), C.c_int(), C.c_int()
             _lib.check(L.tfa_fwd_plan(pref, C.byref(g_), C.byref(b_), C.byref(l_)))
@@ -179,7 +192,10 @@ def main():
             clk_mhz = None
 
     fl, by = C.c_double(), C.c_double()
-    L.tfa_fwd_work(pref, C.byref(fl), C.byref(by))
+    if bwd:
+        L.tfa_bwd_work(pbref, C.byref(fl), C.byref(by))
+    else:
+        L.tfa_fwd_work(pref, C.byref(fl), C.byref(by))
     flops_step_rank = fl.value
     total_flops = flops_step_rank * world * args.steps
     value = total_flops / wall / 1e12
@@ -191,12 +207,12 @@ def main():
         traffic = None
         try:   # HBM bytes per launch from the committed PMC profile of this same command (profiles/)
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if args.variant < 0 and args.config in tj:
+            if args.variant < 0 and args.config in tj and not bwd:
                 traffic = tj[args.config]["bytes"]
         except Exception:
             traffic = None
         line = {
-            "metric": "fwd TFLOPS + achieved %MFMA-roofline, (B=4,H=32,N=4096,D=128) bf16",
+            "metric": ("bwd TFLOPS (2.5 x fwd flops)" if bwd else "fwd TFLOPS") + " + achieved %MFMA-roofline, (B=4,H=32,N=4096,D=128) bf16",
             "value": value,
             "unit": "TFLOP/s",
             "n_gpus": world,
@@ -209,7 +225,7 @@ def main():
             "dtype": "bf16" if dtype == torch.bfloat16 else "f16",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: FlashAttention-2 forward, per-GPU B={B} H={H} N={N} D={D} "
+                "workload": f"{args.config}: FlashAttention-2 {'backward (delta+dQ+dK+dV)' if bwd else 'forward'}, per-GPU B={B} H={H} N={N} D={D} "
                             f"{'causal' if causal else 'full'}, q/k/v normal(0,0.5) resident in HBM, scale=1/sqrt(D)",
                 "global_batch": B * world,
                 "per_gpu_batch": B,
@@ -235,7 +251,7 @@ def main():
                 "hbm_frac": by.value / (ev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not bwd:
             try:
                 line["cpu_baseline"] = cpu_baseline(B, H, N, D, causal)
             except Exception as e:  # the baseline is a report, not the product: never fail the bench on it

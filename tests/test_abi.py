@@ -193,3 +193,40 @@ def test_il_kernels_leave_the_pinned_accumulator_registers_alone():
             bad.append(f"{cur[:60]}: {text.strip()}")
     assert seen > 0, "no fwd_kernel_il code found in the library"
     assert not bad, "compiler-allocated use of the pinned O registers:\n" + "\n".join(bad[:10])
+
+
+def _bwd_params(B=2, H=4, Hk=2, Nq=128, Nk=192, D=128, dtype=_lib.TFA_BF16, grad_dtype=None, base=0x10000):
+    p = _lib.TfaBwdParams()
+    for i, name in enumerate(("q", "k", "v", "out", "dout", "lse", "dq", "dk", "dv", "delta")):
+        setattr(p, name, base * (i + 1))
+    p.B, p.H, p.Hk, p.Nq, p.Nk, p.D = B, H, Hk, Nq, Nk, D
+    for name, (h, n) in (("q_stride", (H, Nq)), ("k_stride", (Hk, Nk)), ("v_stride", (Hk, Nk)), ("o_stride", (H, Nq)),
+                         ("do_stride", (H, Nq)), ("dq_stride", (H, Nq)), ("dk_stride", (Hk, Nk)), ("dv_stride", (Hk, Nk))):
+        a = getattr(p, name)
+        a[0], a[1], a[2] = h * n * D, n * D, D
+    p.softmax_scale = 0.1
+    p.is_causal = 1
+    p.dtype = dtype
+    p.grad_dtype = dtype if grad_dtype is None else grad_dtype
+    return p
+
+
+def test_bwd_descriptor_validation_without_gpu():
+    L = _lib.lib()
+    assert L.tfa_bwd_plan(C.byref(_bwd_params())) == 0
+    assert L.tfa_bwd_plan(C.byref(_bwd_params(grad_dtype=_lib.TFA_F32))) == 0          # fp32 gradients (debug path)
+    assert L.tfa_bwd_plan(C.byref(_bwd_params(dtype=_lib.TFA_BF16, grad_dtype=_lib.TFA_F16))) == -2
+    assert L.tfa_bwd_plan(C.byref(_bwd_params(D=96))) == -3
+    assert L.tfa_bwd_plan(C.byref(_bwd_params(H=4, Hk=3))) == -4
+    p = _bwd_params(); p.delta = None
+    assert L.tfa_bwd_plan(C.byref(p)) == -1
+    p = _bwd_params(); p.dk_stride[2] = 64                                                # rows would overlap
+    assert L.tfa_bwd_plan(C.byref(p)) == -5
+    p = _bwd_params(); p.dout = 0x10008
+    assert L.tfa_bwd_plan(C.byref(p)) == -6
+    # work model: 2.5 x the forward's flops (5 GEMMs), halved when causal
+    f, b = C.c_double(), C.c_double()
+    p = _bwd_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128)
+    assert L.tfa_bwd_work(C.byref(p), C.byref(f), C.byref(b)) == 0
+    assert f.value == pytest.approx(2.5 * 5.498e11, rel=1e-3)
+    assert b.value == pytest.approx(8 * 4 * 32 * 4096 * 128 * 2 + 4 * 4 * 32 * 4096, rel=1e-6)
