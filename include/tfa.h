@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 100 /* 0.1.0 */
+#define TFA_VERSION 101 /* 0.1.0 */
 
 /* element types */
 enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1, TFA_F32 = 2 /* output only */ };
@@ -87,7 +87,13 @@ typedef struct tfa_fwd_params {
   float softmax_scale;
   int32_t is_causal;     /* bottom-right aligned when Nq != Nk */
   int32_t dtype;         /* tfa_dtype of q,k,v: TFA_F16 or TFA_BF16 */
-  int32_t out_dtype;     /* == dtype, or TFA_F32 (debug/parity: unrounded fp32 O) */
+  int32_t out_dtype;     /* == dtype, or TFA_F32 (debug/parity: unrounded fp32 O; also the partial results of split-KV) */
+  /* split-KV: when k, v are the chunk [kv_offset, kv_offset + Nk) of a longer key
+   * sequence of nk_total keys, the causal mask is taken against GLOBAL key positions: key kv_offset + j is
+   * visible to row i iff kv_offset + j <= i + (nk_total - Nq).  out / lse are then PARTIAL results (rows that
+   * see no key of the chunk: out = 0, lse = +inf) to be combined with tfa_merge.  Both 0 = the whole sequence. */
+  int64_t kv_offset;
+  int64_t nk_total;      /* 0 means kv_offset + Nk */
 } tfa_fwd_params;
 
 /* Library version (TFA_VERSION of the build). */
@@ -127,6 +133,16 @@ int tfa_fwd_variant(const tfa_fwd_params* p);
  * (after `warmup` untimed launches).  Writes the average milliseconds per launch.
  * Synchronises `stream`.  Used by bench.py for the roofline numbers. */
 int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, float* avg_ms);
+
+/* ---- split-KV merge ---------------------------------------------------------
+ * Combines `nparts` partial attention results over disjoint key chunks of the same queries — the online-softmax
+ * merge rule the reference states for its v1 form (flash_attention_py/tiny_flash_attn.py:63-68, README_zh.md:104-125):
+ *   lse = log sum_p exp(lse_p),   out = sum_p exp(lse_p - lse) * out_p      (parts with lse_p = +inf are empty).
+ * o_parts: nparts x rows x D fp32 (part stride o_part_stride elements, rows contiguous, rows = B*H*Nq);
+ * lse_parts: nparts x rows fp32 (part stride lse_part_stride).  out: rows x D of out_dtype (F16/BF16/F32),
+ * lse_out: rows fp32 or NULL.  A row whose parts are all empty gives out = 0, lse = +inf. */
+int tfa_merge(const float* o_parts, const float* lse_parts, int nparts, int64_t rows, int D,
+              int64_t o_part_stride, int64_t lse_part_stride, void* out, int out_dtype, float* lse_out, void* stream);
 
 /* ---- backward ------------------------------------------------------------
  * The reference has no backward pass; it saves softmax_lse for one ("LogSumExp save for backward",

@@ -227,6 +227,38 @@ def tiled_emulation_lazy(q, k, v, is_causal, softmax_scale, block_n=64, group=32
     return out
 
 
+def partial_attn(q, k_chunk, v_chunk, is_causal, softmax_scale, kv_offset, nk_total):
+    """fp32 partial attention of all queries over the key chunk [kv_offset, kv_offset+len) of a sequence of
+    ``nk_total`` keys, causal mask against global positions (attn.cpp:121-124 with the chunk offset): returns
+    (O_partial fp32, LSE_partial) with O = 0, LSE = +inf for rows that see no key of the chunk."""
+    qf, kf, vf = (t.detach().cpu().float() for t in (q, k_chunk, v_chunk))
+    H, Hk = qf.shape[1], kf.shape[1]
+    if Hk != H:
+        kf = kf.repeat_interleave(H // Hk, dim=1)
+        vf = vf.repeat_interleave(H // Hk, dim=1)
+    Nq, n = qf.shape[2], kf.shape[2]
+    s = torch.matmul(qf, kf.transpose(2, 3)) * softmax_scale
+    if is_causal:
+        i = torch.arange(Nq)[:, None]
+        j = torch.arange(n)[None, :] + kv_offset
+        s = s.masked_fill(j > i + (nk_total - Nq), float("-inf"))
+    lse = torch.logsumexp(s, dim=-1)
+    p = torch.nan_to_num(torch.softmax(s, dim=-1), nan=0.0)
+    o = torch.matmul(p, vf)
+    lse = torch.where(torch.isneginf(lse), torch.full_like(lse, math.inf), lse)
+    return o, lse
+
+
+def merge_partials(o_parts, lse_parts, dtype=torch.float32):
+    """The reference's v1 merge rule (flash_attention_py/tiny_flash_attn.py:63-68) in LSE form; +inf = empty part."""
+    l = torch.where(torch.isposinf(lse_parts), torch.full_like(lse_parts, -math.inf), lse_parts)
+    tot = torch.logsumexp(l, dim=0)
+    w = torch.nan_to_num(torch.exp(l - tot), nan=0.0)
+    out = (w.unsqueeze(-1) * o_parts).sum(0)
+    tot = torch.where(torch.isneginf(tot), torch.full_like(tot, math.inf), tot)
+    return out.to(dtype), tot
+
+
 def attn_bwd_reference(q, k, v, dout, is_causal, softmax_scale, dtype=torch.float64):
     """Gradients of O = softmax(scale * Q K^T + mask) V w.r.t. q, k, v by autograd on the CPU in ``dtype``
     (fp64 = ground truth) — the function the reference's forward implements (attn.cpp:35-98) differentiated;

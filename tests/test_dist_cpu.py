@@ -73,3 +73,43 @@ def test_shard_bounds():
     assert [shard_bounds(64, 8, r) for r in (0, 7)] == [(0, 8), (56, 64)]          # BASELINE config 5: B=64 over 8 GPUs
     assert [shard_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert shard_axis(64, 32, 8) == "batch" and shard_axis(1, 16, 8) == "bh" and shard_axis(6, 4, 4) == "bh"
+
+
+def _kv_worker(rank, world, port, shape, causal, q_out):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from tiny_flash_attention_amd import dist as tdist
+
+    B, H, Nq, Nk, D = shape
+    q, k, v = O.make_inputs(B, H, Nq, D, torch.float32, seed=23, Nk=Nk)   # same seed on every rank
+    sc = 1.0 / math.sqrt(D)
+    n = Nk // world
+    lo = rank * n
+    out, lse = tdist.kv_sharded_forward(q, k[:, :, lo:lo + n], v[:, :, lo:lo + n], causal, sc, lo, Nk,
+                                        partial_fn=O.partial_attn, merge_fn=O.merge_partials, out_dtype=torch.float32)
+    ref, lse_ref = O.sdpa_reference(q, k, v, causal, sc)
+    fin = torch.isfinite(lse_ref)
+    ok = (out - ref).abs().max().item() < 2e-6 and bool((torch.isinf(lse) == ~fin).all()) and (lse[fin] - lse_ref[fin]).abs().max().item() < 1e-5
+    q_out.put((rank, ok, "kv"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape,causal", [((2, 2, 48, 128, 32), True), ((1, 3, 100, 64, 32), False), ((1, 2, 16, 96, 32), True)])
+def test_kv_sharded_forward_gloo_world2(shape, causal):
+    """split-KV across ranks: partials over each rank's key chunk (global causal positions), all-gather, merge."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_kv_worker, args=(r, 2, port, shape, causal, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res

@@ -1,0 +1,95 @@
+"""GPU tests of split-KV: partial forwards over key chunks (tfa_fwd with kv_offset /
+nk_total, fp32 partial O + LSE) merged by tfa_merge must reproduce the one-pass forward.
+
+Tolerances: partial O is fp32, so after the merge the 16-bit result may differ from the one-pass kernel's only by
+the different rounding points of P (tile boundaries are the same, the running reference differs per chunk):
+(S1) vs the fp64 oracle the same bars as the forward (T1: 1e-2 for 16-bit out; T5: LSE 1e-4, same +inf pattern);
+(S2) vs the one-pass kernel: |d| <= 2 ulp16 of the result + 2^-8 * A (A = sum_j P|v|);
+(S3) tfa_merge alone vs the oracle's merge on identical fp32 partials: 1e-6 relative.
+"""
+import math
+
+import pytest
+import torch
+
+from helpers import ulp16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("variant", [-1, 27, 30])
+@pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D,causal,splits", [
+    (torch.bfloat16, 1, 4, 4, 512, 512, 128, True, 2),
+    (torch.bfloat16, 2, 4, 2, 300, 1000, 128, True, 3),      # GQA, ragged, Nq < Nk
+    (torch.float16, 1, 2, 2, 700, 256, 64, True, 4),         # chunks that many rows cannot see at all
+    (torch.float16, 1, 2, 1, 333, 777, 64, False, 5),
+    (torch.bfloat16, 1, 1, 1, 1, 2048, 128, True, 8),        # decode-like: one query row, 8 key chunks
+])
+def test_splitkv_matches_one_pass(oracle, dev, variant, dtype, B, H, Hk, Nq, Nk, D, causal, splits):
+    from tiny_flash_attention_amd import _lib, ops
+
+    q, k, v = oracle.make_inputs(B, H, Nq, D, dtype, seed=31, Hk=Hk, Nk=Nk)
+    sc = 1.0 / math.sqrt(D)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    _lib.set_variant(variant)
+    try:
+        full, lse_full = ops.flash_attn_fwd(qd, kd, vd, causal, sc)
+        out, lse = ops.flash_attn_fwd_splitkv(qd, kd, vd, causal, sc, splits=splits)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_variant(-1)
+    exact, lse_x = oracle.exact64(q, k, v, causal, sc, return_lse=True)
+    A = oracle.abs_weighted(q, k, v, causal, sc)
+    o = out.float().cpu()
+    assert bool(torch.isfinite(o).all())
+    assert (o - exact).abs().max().item() <= 1e-2                                                  # (S1)
+    fin = torch.isfinite(lse_x)
+    assert bool((torch.isinf(lse.cpu()) == ~fin).all())
+    if fin.any():
+        assert (lse.cpu()[fin] - lse_x[fin]).abs().max().item() <= 1e-4
+    d = (o - full.float().cpu()).abs()
+    assert bool((d <= 2 * ulp16(exact, dtype) + 2.0 ** -8 * A + 1e-6).all())                       # (S2)
+    assert torch.equal(torch.isinf(lse), torch.isinf(lse_full))
+
+
+def test_merge_kernel_vs_oracle(oracle, dev):
+    from tiny_flash_attention_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    P, B, H, N, D = 5, 2, 3, 77, 128
+    o_parts = torch.empty((P, B, H, N, D)).normal_(0, 1, generator=g)
+    lse_parts = torch.empty((P, B, H, N)).normal_(0, 3, generator=g)
+    lse_parts[1, :, :, :10] = math.inf            # empty parts for some rows
+    lse_parts[:, 0, 0, 5] = math.inf              # a row whose parts are all empty
+    o_parts[:, 0, 0, 5] = 0
+    ref, lref = oracle.merge_partials(o_parts, lse_parts)
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        out, lse = ops.merge_partials(o_parts.to(dev), lse_parts.to(dev), dt)
+        torch.cuda.synchronize()
+        tol = 1e-6 if dt == torch.float32 else (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11)
+        assert ((out.float().cpu() - ref).abs() <= tol * ref.abs() + 1e-6).all()                   # (S3)
+        fin = torch.isfinite(lref)
+        assert bool((torch.isinf(lse.cpu()) == ~fin).all()) and (lse.cpu()[fin] - lref[fin]).abs().max().item() <= 1e-5
+        assert float(out[0, 0, 5].float().abs().max()) == 0.0
+
+
+def test_partial_forward_semantics(oracle, dev):
+    # one chunk in the middle of a causal sequence: rows above the chunk see nothing (O = 0, LSE = +inf)
+    from tiny_flash_attention_amd import ops
+
+    q, k, v = oracle.make_inputs(1, 2, 512, 128, torch.bfloat16, seed=8)
+    lo, hi = 192, 384
+    o32, lse = ops.flash_attn_fwd(q.to(dev), k[:, :, lo:hi].to(dev), v[:, :, lo:hi].to(dev), True, 0.088, out_f32=True, kv_offset=lo, nk_total=512)
+    torch.cuda.synchronize()
+    ref, lref = oracle.partial_attn(q, k[:, :, lo:hi], v[:, :, lo:hi], True, 0.088, lo, 512)
+    assert bool(torch.isinf(lse[:, :, :lo]).all()) and float(o32[:, :, :lo].abs().max()) == 0.0
+    assert bool((torch.isinf(lse.cpu()) == torch.isinf(lref)).all())
+    fin = torch.isfinite(lref)
+    assert (lse.cpu()[fin] - lref[fin]).abs().max().item() <= 1e-4
+    assert (o32.cpu() - ref).abs().max().item() <= 1e-2

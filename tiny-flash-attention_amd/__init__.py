@@ -21,6 +21,8 @@ from .ops import (  # noqa: F401
     flash_attn_func,
     flash_attn_fwd,
     flash_attn_bwd,
+    flash_attn_fwd_splitkv,
+    merge_partials,
 )
 from . import _lib  # noqa: F401
 
@@ -34,4 +36,6 @@ __all__ = [
     "flash_attn_func",
     "flash_attn_fwd",
     "flash_attn_bwd",
+    "flash_attn_fwd_splitkv",
+    "merge_partials",
 ]

@@ -24,6 +24,7 @@ SYMBOLS = (
     "tfa_variant_name",
     "tfa_fwd_work",
     "tfa_debug_set_trace",
+    "tfa_merge",
     "tfa_bwd",
     "tfa_bwd_plan",
     "tfa_bwd_work",
@@ -54,6 +55,8 @@ class TfaFwdParams(C.Structure):
         ("is_causal", C.c_int32),
         ("dtype", C.c_int32),
         ("out_dtype", C.c_int32),
+        ("kv_offset", C.c_int64),
+        ("nk_total", C.c_int64),
     ]
 
 
@@ -137,6 +140,8 @@ def lib():
     L.tfa_variant_name.argtypes = [C.c_int]
     L.tfa_debug_set_trace.restype = C.c_int
     L.tfa_debug_set_trace.argtypes = [C.c_void_p]
+    L.tfa_merge.restype = C.c_int
+    L.tfa_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     PB = C.POINTER(TfaBwdParams)
     L.tfa_bwd.restype = C.c_int
     L.tfa_bwd.argtypes = [PB, C.c_void_p]

@@ -90,6 +90,12 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   memset(a, 0, sizeof(*a));
   a->q = p->q; a->k = p->k; a->v = p->v; a->o = p->out; a->lse = p->lse;
   a->B = p->B; a->H = p->H; a->Hk = p->Hk; a->Nq = p->Nq; a->Nk = p->Nk;
+  {
+    if (p->kv_offset < 0 || p->nk_total < 0) return TFA_ERR_SHAPE;
+    const int64_t total = p->nk_total ? p->nk_total : (p->kv_offset + p->Nk);
+    if (p->kv_offset + p->Nk > total || total - p->Nq - p->kv_offset < -(int64_t)0x3fffffff || total >= (int64_t)0x3fffffff) return TFA_ERR_SHAPE;
+    a->shift = (int)(total - p->Nq - p->kv_offset);
+  }
   a->qs_b = p->q_stride[0]; a->qs_h = p->q_stride[1]; a->qs_n = p->q_stride[2];
   a->ks_b = p->k_stride[0]; a->ks_h = p->k_stride[1]; a->ks_n = p->k_stride[2];
   a->vs_b = p->v_stride[0]; a->vs_h = p->v_stride[1]; a->vs_n = p->v_stride[2];

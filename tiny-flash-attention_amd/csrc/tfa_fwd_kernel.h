@@ -43,6 +43,8 @@ struct KArgs {
   void* o;
   float* lse;
   int B, H, Hk, Nq, Nk;
+  int shift;        // causal: key j of THIS K/V tensor is visible to row i iff j <= i + shift
+                    // (= Nk - Nq bottom-right aligned; less the chunk offset when K/V is a chunk of a longer sequence)
   int nmb;          // number of query blocks per (b,h)
   int nwork;        // work items per (b,h): nmb, or ceil(nmb/2) when causal blocks are paired
   int nbh;          // B*H
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(NW * 64, RB == 1 ? 2 : 1) void fwd_kernel(const KAr
   const int b = bh / p.H;
   const int h = bh - b * p.H;
   const int hk = h / (p.H / p.Hk);
-  const int shift = p.Nk - p.Nq;           // causal: key j visible to row i iff j <= i + shift
+  const int shift = p.shift;           // causal: key j visible to row i iff j <= i + shift
 
   const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
   const T* kbase = reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 31;
   const int hi = lane >> 5;
-  const int shift = p.Nk - p.Nq;
+  const int shift = p.shift;
   const int nitems = p.nbh * p.nwork;
 
   // ---- per-lane DMA source offsets (tile 0); the LDS destination of piece pc is pc*1024 + lane*16

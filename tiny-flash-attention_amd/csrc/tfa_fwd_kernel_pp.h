@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel_pp(const KArgs p) {
   const int b = bh / p.H;
   const int h = bh - b * p.H;
   const int hk = h / (p.H / p.Hk);
-  const int shift = p.Nk - p.Nq;
+  const int shift = p.shift;
 
   const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
   const T* kbase = reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h;

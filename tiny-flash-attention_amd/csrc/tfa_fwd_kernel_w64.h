@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 31;
   const int hi = lane >> 5;
-  const int shift = p.Nk - p.Nq;
+  const int shift = p.shift;
 
   int bh, wi;
   {

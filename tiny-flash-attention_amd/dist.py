@@ -60,3 +60,30 @@ def sharded_forward(q, k, v, is_causal, softmax_scale, group=None, gather=True, 
     full = torch.empty(q.shape, dtype=out_l.dtype, device=out_l.device)
     dist.all_gather_into_tensor(full.view(-1), out_l.contiguous().view(-1), group=group)
     return full
+
+
+def kv_sharded_forward(q, k_local, v_local, is_causal, softmax_scale, kv_offset, nk_total, group=None,
+                       partial_fn=None, merge_fn=None, out_dtype=None):
+    """Split-KV across ranks (long context): every rank holds the same queries
+    ``q`` (B,H,Nq,D) and ITS chunk ``k_local``/``v_local`` = keys [kv_offset, kv_offset+Nk_local) of a sequence of
+    ``nk_total`` keys (equal chunk sizes across ranks).  Each rank computes the partial attention of all queries
+    over its chunk (fp32 O + LSE; causal mask against global key positions), the partials are all-gathered
+    (the one collective: world x (B*H*Nq*(D+1)) floats per rank over xGMI) and merged locally with the
+    online-softmax rule, so every rank returns the full ``(out, lse)``.
+    ``partial_fn(q,k,v,causal,scale,kv_offset,nk_total) -> (o32, lse)`` and ``merge_fn(o_parts, lse_parts, dtype)``
+    default to the HIP operators; the CPU tests inject oracle functions."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if partial_fn is None:
+        partial_fn = lambda a, b_, c, cz, sc, off, tot: ops.flash_attn_fwd(a, b_, c, cz, sc, out_f32=True, kv_offset=off, nk_total=tot)
+    if merge_fn is None:
+        merge_fn = ops.merge_partials
+    out_dtype = q.dtype if out_dtype is None else out_dtype
+    o_l, l_l = partial_fn(q, k_local, v_local, is_causal, softmax_scale, kv_offset, nk_total)
+    o_l, l_l = o_l.contiguous(), l_l.contiguous()
+    if world == 1:
+        return merge_fn(o_l.unsqueeze(0), l_l.unsqueeze(0), out_dtype)
+    o_all = torch.empty((world,) + tuple(o_l.shape), dtype=o_l.dtype, device=o_l.device)
+    l_all = torch.empty((world,) + tuple(l_l.shape), dtype=l_l.dtype, device=l_l.device)
+    dist.all_gather_into_tensor(o_all.view(-1), o_l.view(-1), group=group)
+    dist.all_gather_into_tensor(l_all.view(-1), l_l.view(-1), group=group)
+    return merge_fn(o_all, l_all, out_dtype)

@@ -32,7 +32,7 @@ def _strides_bhnd(t, layout):
 
 
 def flash_attn_fwd(q, k, v, is_causal=False, softmax_scale=None, *, layout="bhnd", out_f32=False,
-                   return_lse=True, out=None):
+                   return_lse=True, out=None, kv_offset=0, nk_total=None):
     """General forward: q (B,H,Nq,D) / k,v (B,Hk,Nk,D) for ``layout='bhnd'`` or
     (B,N,H,D) for ``layout='bnhd'``; any batch/head/row strides, unit stride along D.
     Returns ``(out, lse)``; ``out`` has q's shape (fp32 when ``out_f32``), ``lse`` is (B,H,Nq) fp32.
@@ -76,10 +76,49 @@ def flash_attn_fwd(q, k, v, is_causal=False, softmax_scale=None, *, layout="bhnd
     p.is_causal = 1 if is_causal else 0
     p.dtype = _DT[q.dtype]
     p.out_dtype = _lib.TFA_F32 if out.dtype == torch.float32 else _DT[out.dtype]
+    p.kv_offset = int(kv_offset)                     # split-KV: k, v are keys [kv_offset, kv_offset+Nk) of nk_total
+    p.nk_total = 0 if nk_total is None else int(nk_total)
     with torch.cuda.device(q.device):
         stream = torch.cuda.current_stream().cuda_stream
         _lib.check(_lib.lib().tfa_fwd(C.byref(p), C.c_void_p(stream)))
     return out, lse
+
+
+def merge_partials(o_parts, lse_parts, out_dtype=torch.bfloat16):
+    """Split-KV merge (tfa_merge): ``o_parts`` (P,B,H,Nq,D) fp32 and ``lse_parts`` (P,B,H,Nq) fp32 are partial
+    attention results of the same queries over disjoint key chunks (``flash_attn_fwd(..., out_f32=True,
+    kv_offset=..., nk_total=...)``); returns ``(out, lse)`` of the whole key sequence.  The rule is the reference's
+    v1 merge (flash_attention_py/tiny_flash_attn.py:63-68) in LSE form."""
+    if not o_parts.is_cuda or o_parts.dtype != torch.float32 or lse_parts.dtype != torch.float32:
+        raise RuntimeError("o_parts / lse_parts must be fp32 CUDA tensors")
+    o_parts, lse_parts = o_parts.contiguous(), lse_parts.contiguous()
+    P, D = o_parts.shape[0], o_parts.shape[-1]
+    rows = lse_parts[0].numel()
+    if o_parts[0].numel() != rows * D or lse_parts.shape[0] != P:
+        raise RuntimeError("shape mismatch between o_parts and lse_parts")
+    out = torch.empty(o_parts.shape[1:], dtype=out_dtype, device=o_parts.device)
+    lse = torch.empty(lse_parts.shape[1:], dtype=torch.float32, device=o_parts.device)
+    code = _lib.TFA_F32 if out_dtype == torch.float32 else _DT[out_dtype]
+    with torch.cuda.device(o_parts.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().tfa_merge(o_parts.data_ptr(), lse_parts.data_ptr(), P, rows, D, rows * D, rows,
+                                        out.data_ptr(), code, lse.data_ptr(), C.c_void_p(stream)))
+    return out, lse
+
+
+def flash_attn_fwd_splitkv(q, k, v, is_causal=False, softmax_scale=None, *, splits=2, return_lse=True):
+    """The forward as `splits` partial passes over contiguous key chunks (multiples of 64 keys) + tfa_merge.
+    Single-GPU form of split-KV (the multi-GPU form is dist.kv_sharded_forward); (B,H,N,D) layout."""
+    Nk = k.shape[2]
+    step = ((Nk + splits - 1) // splits + 63) // 64 * 64
+    o_parts, l_parts = [], []
+    for lo in range(0, Nk, step):
+        hi = min(Nk, lo + step)
+        o, l = flash_attn_fwd(q, k[:, :, lo:hi], v[:, :, lo:hi], is_causal, softmax_scale, out_f32=True, kv_offset=lo, nk_total=Nk)
+        o_parts.append(o)
+        l_parts.append(l)
+    out, lse = merge_partials(torch.stack(o_parts), torch.stack(l_parts), q.dtype)
+    return (out, lse) if return_lse else out
 
 
 def make_params(q, k, v, out, lse, is_causal, softmax_scale, layout="bhnd"):
