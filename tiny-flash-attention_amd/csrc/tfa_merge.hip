@@ -27,11 +27,13 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* __restrict__ o_
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float wsum = 0.f;
   if (m != -INFINITY) {
+    // branch-free body (an empty part gets weight 0; tfa_fwd writes O = 0 for it) so that the loads of several parts
+    // are in flight together: the kernel is a pure HBM stream
+#pragma unroll 8
     for (int p = 0; p < nparts; ++p) {
       const float l = lse_parts[p * lstride + row];
-      if (l == INFINITY) continue;
-      const float w = __expf(l - m);
-      const f32x4 o = *reinterpret_cast<const f32x4*>(o_parts + p * ostride + row * D + c * 4);
+      const f32x4 o = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(o_parts + p * ostride + row * D + c * 4));
+      const float w = (l == INFINITY) ? 0.f : __expf(l - m);
       acc += w * o;
       wsum += w;
     }
