@@ -144,6 +144,13 @@ int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, f
 int tfa_merge(const float* o_parts, const float* lse_parts, int nparts, int64_t rows, int D,
               int64_t o_part_stride, int64_t lse_part_stride, void* out, int out_dtype, float* lse_out, void* stream);
 
+/* Split-KV on one GPU in ONE launch (decode-like shapes: few query rows, long K/V, too few workgroups to fill the
+ * chip): the key sequence is cut into `splits` chunks (multiples of 64 keys), the grid carries one copy of the work per
+ * chunk (LDS-DMA kernel), partials go to `workspace`, tfa_merge writes *p's out (contiguous (B,H,Nq,D)) and lse.
+ * workspace: tfa_fwd_splitkv_workspace(p, splits) floats (16-byte aligned); negative return = TFA_ERR_*. */
+long long tfa_fwd_splitkv_workspace(const tfa_fwd_params* p, int splits);
+int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void* stream);
+
 /* ---- backward ------------------------------------------------------------
  * The reference has no backward pass; it saves softmax_lse for one ("LogSumExp save for backward",
  * flash_attention_cutlass/csrc/flash_attention.cu:353-354, :614-623; tiny_flash_attn_triton.py:27-29).

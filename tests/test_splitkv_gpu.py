@@ -23,7 +23,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("variant", [-1, 27, 30])
+@pytest.mark.parametrize("variant", [-1, 27, 30, "native"])      # "native": tfa_fwd_splitkv, all chunks in one launch
 @pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D,causal,splits", [
     (torch.bfloat16, 1, 4, 4, 512, 512, 128, True, 2),
     (torch.bfloat16, 2, 4, 2, 300, 1000, 128, True, 3),      # GQA, ragged, Nq < Nk
@@ -37,10 +37,11 @@ def test_splitkv_matches_one_pass(oracle, dev, variant, dtype, B, H, Hk, Nq, Nk,
     q, k, v = oracle.make_inputs(B, H, Nq, D, dtype, seed=31, Hk=Hk, Nk=Nk)
     sc = 1.0 / math.sqrt(D)
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
-    _lib.set_variant(variant)
+    native = variant == "native"
+    _lib.set_variant(-1 if native else variant)
     try:
         full, lse_full = ops.flash_attn_fwd(qd, kd, vd, causal, sc)
-        out, lse = ops.flash_attn_fwd_splitkv(qd, kd, vd, causal, sc, splits=splits)
+        out, lse = ops.flash_attn_fwd_splitkv(qd, kd, vd, causal, sc, splits=splits, native=native)
         torch.cuda.synchronize()
     finally:
         _lib.set_variant(-1)

@@ -25,6 +25,8 @@ SYMBOLS = (
     "tfa_fwd_work",
     "tfa_debug_set_trace",
     "tfa_merge",
+    "tfa_fwd_splitkv",
+    "tfa_fwd_splitkv_workspace",
     "tfa_bwd",
     "tfa_bwd_plan",
     "tfa_bwd_work",
@@ -140,6 +142,10 @@ def lib():
     L.tfa_variant_name.argtypes = [C.c_int]
     L.tfa_debug_set_trace.restype = C.c_int
     L.tfa_debug_set_trace.argtypes = [C.c_void_p]
+    L.tfa_fwd_splitkv.restype = C.c_int
+    L.tfa_fwd_splitkv.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p]
+    L.tfa_fwd_splitkv_workspace.restype = C.c_longlong
+    L.tfa_fwd_splitkv_workspace.argtypes = [P, C.c_int]
     L.tfa_merge.restype = C.c_int
     L.tfa_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     PB = C.POINTER(TfaBwdParams)

@@ -196,6 +196,60 @@ int tfa_fwd_plan(const tfa_fwd_params* p, int* grid, int* block, int* lds_bytes)
   return TFA_OK;
 }
 
+// ---- split-KV in one launch ------------------------------------------------------------------------------------------
+static int splitkv_geometry(const tfa_fwd_params* p, int splits, int* nsplit, int* chunk) {
+  if (!p || splits < 1) return TFA_ERR_SHAPE;
+  if (p->kv_offset != 0 || p->nk_total != 0) return TFA_ERR_SHAPE;          // the call splits the WHOLE key sequence
+  int c = (p->Nk + splits - 1) / splits;
+  c = (c + 63) / 64 * 64;
+  *chunk = c;
+  *nsplit = (p->Nk + c - 1) / c;
+  return TFA_OK;
+}
+
+long long tfa_fwd_splitkv_workspace(const tfa_fwd_params* p, int splits) {
+  int ns = 0, ch = 0;
+  const int st = splitkv_geometry(p, splits, &ns, &ch);
+  if (st != TFA_OK) return st;
+  const long long rows = (long long)p->B * p->H * p->Nq;
+  return (long long)ns * rows * (p->D + 1);
+}
+
+int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void* stream) {
+  int ns = 0, ch = 0;
+  int st = splitkv_geometry(p, splits, &ns, &ch);
+  if (st != TFA_OK) return st;
+  if (!workspace || ((uintptr_t)workspace & 15)) return workspace ? TFA_ERR_ALIGN : TFA_ERR_NULL;
+  // the merge writes contiguous rows: out must be a contiguous (B,H,Nq,D) tensor
+  if (p->o_stride[2] != p->D || p->o_stride[1] != (int64_t)p->Nq * p->D || p->o_stride[0] != (int64_t)p->H * p->Nq * p->D) return TFA_ERR_STRIDE;
+  const long long rows = (long long)p->B * p->H * p->Nq;
+  float* ws_o = workspace;
+  float* ws_l = workspace + (long long)ns * rows * p->D;
+  tfa_fwd_params q = *p;                                  // the partial pass: fp32 O and LSE of every chunk into the workspace
+  q.out = ws_o;
+  q.lse = ws_l;
+  q.out_dtype = TFA_F32;
+  q.o_stride[0] = (int64_t)p->H * p->Nq * p->D; q.o_stride[1] = (int64_t)p->Nq * p->D; q.o_stride[2] = p->D;
+  const int variant = tfa::kSmallGridVariant;             // the LDS-DMA kernel carries the chunk dimension in its grid
+  tfa::KArgs a;
+  st = validate(&q, &a, variant);
+  if (st != TFA_OK) return st;
+  a.nsplit = ns;
+  a.chunk = ch;
+  a.o_part_stride = rows * p->D;
+  a.lse_part_stride = rows;
+  if ((long long)a.nbh * a.nwork * ns >= (long long)0x7fffffff) return TFA_ERR_SHAPE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipError_t e;
+  const bool causal = p->is_causal != 0;
+  if (p->dtype == TFA_BF16)
+    e = (p->D == 128) ? tfa::launch_fwd<__bf16, 128>(a, causal, true, variant, s, nullptr, false) : tfa::launch_fwd<__bf16, 64>(a, causal, true, variant, s, nullptr, false);
+  else
+    e = (p->D == 128) ? tfa::launch_fwd<_Float16, 128>(a, causal, true, variant, s, nullptr, false) : tfa::launch_fwd<_Float16, 64>(a, causal, true, variant, s, nullptr, false);
+  if (e != hipSuccess) return (int)e;
+  return tfa_merge(ws_o, ws_l, ns, rows, p->D, rows * p->D, rows, p->out, p->out_dtype, p->lse, stream);
+}
+
 int tfa_fwd_variant(const tfa_fwd_params* p) {
   tfa::LaunchGeom g = {0, 0, 0};
   const int st = run(p, nullptr, &g, true);

@@ -45,6 +45,9 @@ struct KArgs {
   int B, H, Hk, Nq, Nk;
   int shift;        // causal: key j of THIS K/V tensor is visible to row i iff j <= i + shift
                     // (= Nk - Nq bottom-right aligned; less the chunk offset when K/V is a chunk of a longer sequence)
+  int nsplit;       // split-KV in one launch (tfa_fwd_splitkv; LDS-DMA kernel only): number of key chunks, 0/1 = none
+  int chunk;        // keys per chunk (multiple of 64)
+  long long o_part_stride, lse_part_stride;   // elements between the partial results of consecutive chunks
   int nmb;          // number of query blocks per (b,h)
   int nwork;        // work items per (b,h): nmb, or ceil(nmb/2) when causal blocks are paired
   int nbh;          // B*H

@@ -76,8 +76,12 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 31;
   const int hi = lane >> 5;
-  const int shift = p.shift;
-  const int nitems = p.nbh * p.nwork;
+  // split-KV in ONE launch (tfa_fwd_splitkv): the grid carries nsplit copies of the work items; copy sp handles the key
+  // chunk [sp*chunk, sp*chunk + nk) with the causal shift reduced by the chunk offset and writes its fp32 partial O and
+  // LSE at sp * part stride.  nsplit <= 1: one chunk = the whole K/V tensor.
+  const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
+  const int nitems0 = p.nbh * p.nwork;
+  const int nitems = nitems0 * nsplit;
 
   // ---- per-lane DMA source offsets (tile 0); the LDS destination of piece pc is pc*1024 + lane*16
   int k_src[PPW], v_src[PPW];
@@ -109,9 +113,19 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
   // ---- the block stream ----------------------------------------------------------------------
   struct Blk {
     int bh, wi, mb, nt;
+    int sp, nk, shift;          // key chunk index, keys in the chunk, causal shift against the chunk's local key index
     __amdgpu_buffer_rsrc_t q_rs, k_rs, v_rs;
   };
-  auto decode = [&](int item, int pass, Blk& k) {
+  auto decode = [&](int item_all, int pass, Blk& k) {
+    k.sp = item_all / nitems0;
+    const int item = item_all - k.sp * nitems0;
+    k.nk = p.Nk;
+    k.shift = p.shift;
+    if (nsplit > 1) {
+      const int rest = p.Nk - k.sp * p.chunk;
+      k.nk = rest < p.chunk ? (rest > 0 ? rest : 0) : p.chunk;
+      k.shift = p.shift - k.sp * p.chunk;
+    }
     if ((p.nbh & 7) == 0) {          // heads of one XCD stay together (item & 7 == blockIdx & 7 when G % 8 == 0)
       const int x = item & 7, s = item >> 3;
       k.bh = x + 8 * (s / p.nwork);
@@ -122,16 +136,24 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
     }
     if (PAIR) k.mb = pass == 0 ? (p.nmb - 1 - k.wi) : k.wi;     // heavy block first, then the light one
     else k.mb = CAUSAL ? (p.nmb - 1 - k.wi) : k.wi;
-    int kv_end = p.Nk;
+    int kv_end = k.nk;
     if (CAUSAL) {
-      const int lim = k.mb * BM + BM + shift;                    // one past the last key any row of the block sees
+      const int lim = k.mb * BM + BM + k.shift;                  // one past the last key any row of the block sees
       kv_end = lim < kv_end ? lim : kv_end;
     }
     k.nt = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
     const int b = k.bh / p.H, h = k.bh - b * p.H, hk = h / (p.H / p.Hk);
     k.q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h), 0, p.q_bytes, 0x00020000);
-    k.k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h), 0, p.k_bytes, 0x00020000);
-    k.v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h), 0, p.v_bytes, 0x00020000);
+    unsigned kb = p.k_bytes, vb = p.v_bytes;
+    long long koff = 0, voff = 0;
+    if (nsplit > 1) {                                            // descriptor over the chunk only: OOB rows read as zeros
+      koff = (long long)k.sp * p.chunk * p.ks_n;
+      voff = (long long)k.sp * p.chunk * p.vs_n;
+      kb = k.nk > 0 ? (unsigned)(((long long)(k.nk - 1) * p.ks_n + D) * 2) : 0u;
+      vb = k.nk > 0 ? (unsigned)(((long long)(k.nk - 1) * p.vs_n + D) * 2) : 0u;
+    }
+    k.k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h + koff), 0, kb, 0x00020000);
+    k.v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h + voff), 0, vb, 0x00020000);
   };
   auto dma_issue = [&](const Blk& k, int j, int buf) {
 #pragma unroll
@@ -183,6 +205,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
     asm volatile("s_barrier" ::: "memory");
     if (p.trace && first) t_pro = __builtin_amdgcn_s_memtime();
 
+    const int shift = cur.shift;
     const int wave_last_tile = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (nt - 1);
 
     auto tile_body = [&](int j, int buf) {
@@ -236,10 +259,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
           }
 
         const int key0 = j * BN;
-        bool need_mask = (key0 + BN > p.Nk);
+        bool need_mask = (key0 + BN > cur.nk);
         if (CAUSAL) need_mask = need_mask || (key0 + BN - 1 > wave_row0 + shift);
         if (need_mask) {
-          int lim = p.Nk - 1;
+          int lim = cur.nk - 1;
           if (CAUSAL) { const int c = my_row + shift; lim = c < lim ? c : lim; }
           lim -= key0 + 4 * hi;
 #pragma unroll
@@ -327,6 +350,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
 
     // ---- next block of the stream ----------------------------------------------------------------
     const int cur_bh = cur.bh;
+    const long long o_part = (long long)cur.sp * p.o_part_stride, lse_part = (long long)cur.sp * p.lse_part_stride;   // 0 unless split
     constexpr bool LDS_EPI = !F32OUT && (VF & VF_LDSEPI);   // 16-bit O goes out through LDS as whole rows
     bool have_next;
     if (PAIR && pass == 0 && (p.nmb - 1 - cur.wi) != cur.wi) {
@@ -349,10 +373,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
     const float inv = empty ? 1.f : 1.f / l_tot;
     if (p.lse != nullptr && hi == 0 && my_row < p.Nq) {
       const float lse = empty ? INFINITY : (m_run * p.scale + __builtin_amdgcn_logf(l_tot) * 0.6931471805599453f);
-      p.lse[(long long)cur_bh * p.Nq + my_row] = lse;
+      p.lse[lse_part + (long long)cur_bh * p.Nq + my_row] = lse;
     }
     if (F32OUT) {
-      float* obase = reinterpret_cast<float*>(p.o) + ob * p.os_b + oh * p.os_h;
+      float* obase = reinterpret_cast<float*>(p.o) + o_part + ob * p.os_b + oh * p.os_h;
       auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
       const int ooff = my_row * (int)p.os_n * 4 + hi * 16;
 #pragma unroll
@@ -367,7 +391,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
       // 16 eight-byte stores per lane to 32 different rows per instruction.  Instead the wave transposes its
       // 32 x D tile through its own slice of the (now idle) K buffers — 16-byte chunk index XOR row, as for K —
       // and writes whole rows: 1 KiB contiguous per store instruction.
-      T* obase = reinterpret_cast<T*>(p.o) + ob * p.os_b + oh * p.os_h;
+      T* obase = reinterpret_cast<T*>(p.o) + o_part + ob * p.os_b + oh * p.os_h;
       auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
       typedef __attribute__((ext_vector_type(4))) T t4;
       char* const ow = smem + wave * (32 * D * 2);
@@ -397,7 +421,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
         prefetch(cur);
       }
     } else {
-      T* obase = reinterpret_cast<T*>(p.o) + ob * p.os_b + oh * p.os_h;
+      T* obase = reinterpret_cast<T*>(p.o) + o_part + ob * p.os_b + oh * p.os_h;
       auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
       const int ooff = my_row * (int)p.os_n * 2 + hi * 8;
       typedef __attribute__((ext_vector_type(4))) T t4;

@@ -106,10 +106,28 @@ def merge_partials(o_parts, lse_parts, out_dtype=torch.bfloat16):
     return out, lse
 
 
-def flash_attn_fwd_splitkv(q, k, v, is_causal=False, softmax_scale=None, *, splits=2, return_lse=True):
-    """The forward as `splits` partial passes over contiguous key chunks (multiples of 64 keys) + tfa_merge.
-    Single-GPU form of split-KV (the multi-GPU form is dist.kv_sharded_forward); (B,H,N,D) layout."""
+def flash_attn_fwd_splitkv(q, k, v, is_causal=False, softmax_scale=None, *, splits=2, return_lse=True, native=True):
+    """The forward as `splits` partial passes over contiguous key chunks (multiples of 64 keys) + tfa_merge;
+    (B,H,N,D) layout, out contiguous.  ``native=True``: tfa_fwd_splitkv — ONE launch whose grid carries a copy of the
+    work per chunk (what decode-like shapes need to fill the chip), partials in a scratch tensor.
+    ``native=False``: one tfa_fwd call per chunk driven from Python (what dist.kv_sharded_forward does per rank)."""
     Nk = k.shape[2]
+    if native:
+        B, H, Nq, D = q.shape
+        if softmax_scale is None:
+            softmax_scale = 1.0 / math.sqrt(D)
+        out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+        p = make_params(q, k, v, out, lse, is_causal, softmax_scale)
+        L = _lib.lib()
+        need = L.tfa_fwd_splitkv_workspace(C.byref(p), int(splits))
+        if need < 0:
+            _lib.check(int(need))
+        ws = torch.empty((int(need),), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(L.tfa_fwd_splitkv(C.byref(p), int(splits), ws.data_ptr(), C.c_void_p(stream)))
+        return (out, lse) if return_lse else out
     step = ((Nk + splits - 1) // splits + 63) // 64 * 64
     o_parts, l_parts = [], []
     for lo in range(0, Nk, step):
