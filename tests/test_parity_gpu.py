@@ -374,3 +374,28 @@ def test_dropin_extension_module_attention_cutlass(tfa, oracle, dev):
         mod.flash_attention_v2_cutlass(q, k, v, True, sm_scale)
     with pytest.raises(TypeError):
         mod.flash_attention_v2_cutlass(qd, kd, vd)          # positional-only, all five required... (no py::arg)
+
+
+def test_hip_graph_capture_and_replay(tfa, oracle, dev):
+    """The C ABI only enqueues kernels on the caller's stream (no allocation, no sync, no host-side state that changes
+    after the first launch), so a forward + backward can be captured into a HIP graph and replayed on new data."""
+    from tiny_flash_attention_amd import ops
+
+    q, k, v = (t.to(dev) for t in oracle.make_inputs(2, 8, 1024, 128, torch.bfloat16, seed=12))
+    dout = torch.randn(q.shape, device=dev, dtype=torch.float32).mul_(0.5).to(torch.bfloat16)
+    sc = 1.0 / math.sqrt(128)
+    out_ref, lse_ref = ops.flash_attn_fwd(q, k, v, True, sc)                       # warm-up (sets the kernels' LDS attribute)
+    g_ref = ops.flash_attn_bwd(q, k, v, out_ref, lse_ref, dout, True, sc)
+    torch.cuda.synchronize()
+    sq, sk, sv, sdo = (torch.zeros_like(t) for t in (q, k, v, dout))               # static graph inputs
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o_g, l_g = ops.flash_attn_fwd(sq, sk, sv, True, sc)
+        dq_g, dk_g, dv_g = ops.flash_attn_bwd(sq, sk, sv, o_g, l_g, sdo, True, sc)
+    for src, dst in ((q, sq), (k, sk), (v, sv), (dout, sdo)):
+        dst.copy_(src)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o_g, out_ref) and torch.equal(l_g, lse_ref)
+    for a, b in zip((dq_g, dk_g, dv_g), g_ref):
+        assert torch.equal(a, b)
