@@ -44,7 +44,17 @@ struct BArgs {
 
 enum { BWD_DQ = 0, BWD_DK = 1, BWD_DV = 2 };
 
-template <typename T, int D, int MODE, bool CAUSAL, bool F32OUT>
+// Unified tile image (UNI, off by default): ONE row-major image per streamed tensor serves both GEMM forms, so a tile costs
+// two LDS images instead of three.  Correct and conflict-free (SQ_LDS_BANK_CONFLICT = 0) but 4 % SLOWER than the
+// three-image version on non-causal shapes (same-process A/B, tools/ab_libs.py --bwd), neutral on causal ones.  The 16-byte chunk index of row r is XORed with u_swz(r): bijective over 16 consecutive
+// rows (ds_read_b128 of GEMM-I: 16 rows x one chunk hit 16 different slots), and for the four consecutive rows a
+// ds_read_b64_tr_b16 group addresses, the 64-byte spans (4 chunks) land in different aligned groups of 4 chunks
+// (D=128), resp. in the other half of the 256-byte bank row (D=64).
+template <int D> static __device__ __forceinline__ int u_swz(int row) {
+  return D == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+}
+
+template <typename T, int D, int MODE, bool CAUSAL, bool F32OUT, bool UNI = false>
 __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
   using E = Elem<T>;
   using X8 = typename E::x8;
@@ -59,8 +69,8 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
   constexpr int DT = D / 32;
   constexpr bool KEYS_RES = MODE != BWD_DQ;        // resident rows are keys
   constexpr bool NEED_DP = MODE != BWD_DV;
-  constexpr int NIMG = MODE == BWD_DV ? 2 : 3;     // LDS images per tile
-  constexpr int IMG_TR = NIMG - 1;                 // the image in the V (transpose-read) layout
+  constexpr int NIMG = (UNI || MODE == BWD_DV) ? 2 : 3;   // LDS images per tile
+  constexpr int IMG_TR = UNI ? (MODE == BWD_DV ? 1 : 0) : NIMG - 1;   // the image GEMM-II reads (UNI: dQ: K, dK: Q, dV: dO)
   static_assert(PPW >= 1 && PPW * NW == PIECES, "");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -133,7 +143,11 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int pc = wave * PPW + i;
-      if (img != IMG_TR) {                           // K layout
+      if (UNI) {                                     // unified row-major image
+        const int row = pc * (1024 / (D * 2)) + lane / CPR;
+        const int cpos = lane % CPR;
+        src[img][i] = row * sn * 2 + ((cpos ^ u_swz<D>(row)) << 4);
+      } else if (img != IMG_TR) {                    // K layout
         const int row = pc * (1024 / (D * 2)) + lane / CPR;
         const int cpos = lane % CPR;
         src[img][i] = row * sn * 2 + ((cpos ^ k_swz<D>(row)) << 4);
@@ -194,9 +208,16 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
   const int k_rd_base = qi * (D * 2);
-  const int k_rd_swz = k_swz<D>(qi);
+  const int k_rd_swz = UNI ? u_swz<D>(qi) : k_swz<D>(qi);
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
   const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
+  // UNI transpose reads: this lane addresses 4 consecutive d (8 bytes) of tile row 16*sl + tr_row (first read) and
+  // 16*sl + tr_row + 8 (second read); chunk = 4*dtile + tr_clo, XOR-swizzled by the row
+  const int tr_row = 4 * hi + (i16 >> 2);
+  const int tr_clo = 2 * g16 + ((i16 & 3) >> 1);
+  const int tr_byte = ((i16 & 3) & 1) * 8;
+  const int tr_s1 = u_swz<D>(tr_row), tr_s2 = u_swz<D>(tr_row + 8);
+  const int tr_b1 = tr_row * (D * 2) + tr_byte, tr_b2 = (tr_row + 8) * (D * 2) + tr_byte;
   const float sc = p.scale_log2;
 
   if (nu > 0) dma_issue(0, 0);
@@ -305,9 +326,16 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
       for (int sl = 2 * t; sl < 2 * t + 2; ++sl)
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
+          s16x4 lo, hh;
+          if (UNI) {
+            const int c = 4 * d + tr_clo;
+            lo = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b1 + ((c ^ tr_s1) << 4));
+            hh = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b2 + ((c ^ tr_s2) << 4));
+          } else {
           const char* a = imgt + v_rd_base + (sl * 2 * DT << 9) + (d << 9);
-          s16x4 lo = lds_read_tr16_b64(a);
-          s16x4 hh = lds_read_tr16_b64(a + 256);
+          lo = lds_read_tr16_b64(a);
+          hh = lds_read_tr16_b64(a + 256);
+          }
           s16x8 vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
           acc[d] = E::mfma(__builtin_bit_cast(X8, vf), pk[sl], acc[d]);
         }

@@ -15,6 +15,7 @@ ap.add_argument("--variant-b", type=int, default=None)
 ap.add_argument("--cfgs", default="cfg3,cfg4")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=40)
+ap.add_argument("--bwd", action="store_true", help="time tfa_bwd instead of tfa_fwd")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 P = C.POINTER(_lib.TfaFwdParams)
@@ -23,6 +24,8 @@ for path in a.libs:
     L = C.CDLL(os.path.abspath(path))
     L.tfa_fwd_time.argtypes = [P, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
     L.tfa_set_variant.argtypes = [C.c_int]
+    if a.bwd:
+        L.tfa_bwd_time.argtypes = [C.POINTER(_lib.TfaBwdParams), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
     Ls.append(L)
 va = a.variant
 vb = a.variant if a.variant_b is None else a.variant_b
@@ -35,12 +38,18 @@ for cfg in a.cfgs.split(","):
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fl, by = C.c_double(), C.c_double()
     _lib.lib().tfa_fwd_work(C.byref(p), C.byref(fl), C.byref(by))
+    if a.bwd:
+        _lib.check(_lib.lib().tfa_fwd(C.byref(p), s))
+        dout = mk()
+        dq, dk, dv, delta = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty_like(lse)
+        pb = ops.make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, causal, 1 / math.sqrt(D))
+        _lib.lib().tfa_bwd_work(C.byref(pb), C.byref(fl), C.byref(by))
     res = [[], []]
     for r in range(a.rounds + 1):
         for i, (L, var) in enumerate(zip(Ls, (va, vb))):
             assert L.tfa_set_variant(var) == 0
             ms = C.c_float()
-            st = L.tfa_fwd_time(C.byref(p), 2, a.iters, s, C.byref(ms))
+            st = L.tfa_bwd_time(C.byref(pb), 2, a.iters, s, C.byref(ms)) if a.bwd else L.tfa_fwd_time(C.byref(p), 2, a.iters, s, C.byref(ms))
             assert st == 0, st
             if r:
                 res[i].append(fl.value / (ms.value * 1e-3) / 1e12)
