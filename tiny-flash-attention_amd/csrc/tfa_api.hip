@@ -47,9 +47,8 @@ int pick_variant(const tfa_fwd_params* p) {
   // The issue-interleaved kernel (tfa_fwd_kernel_il.h) wins wherever the grid fills the chip (+5..11% at D=128).
   const long long blocks256 = (long long)p->B * p->H * ((p->Nq + 255) / 256);
   if (blocks256 < 512) return tfa::kSmallGridVariant;
-  // short causal sequences: a pass is only a few tiles long, so the prologue/epilogue of one 4-wave workgroup is better
-  // hidden behind the second workgroup on the CU (N=2048: 830 vs 819 TF, N=1024: 647 vs 600; N=4096: 979 vs 1020)
-  if (p->is_causal && p->Nq <= 2048) return tfa::kShortCausalVariant;
+  // (with O leaving through LDS the 8-wave il kernel also wins on short sequences: N=512..2048, causal or not, it beats
+  //  the 4-wave one by 3-5 %, tools/ab.py n512/n1k/n2k configs)
   return tfa::kDefaultVariant;
 }
 

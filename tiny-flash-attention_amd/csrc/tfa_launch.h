@@ -54,7 +54,6 @@ static const Variant kVariants[] = {
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
-constexpr int kShortCausalVariant = 27;  // il4-pair (128-row query blocks, two workgroups per CU)
 constexpr int kSmallGridVariant = 17;   // dma4-pair-2buf (128-row query blocks, two workgroups per CU)
 
 struct LaunchGeom {

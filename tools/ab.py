@@ -19,7 +19,10 @@ CFG = {"cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096,
        "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg2": (4, 8, 1024, 64, torch.float16, False),
        "cfg2c": (4, 8, 1024, 64, torch.float16, True), "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),
        "d64": (4, 32, 4096, 64, torch.float16, False), "d64c": (4, 32, 4096, 64, torch.float16, True),
-       "n2k": (8, 32, 2048, 128, torch.bfloat16, True), "n1k": (16, 32, 1024, 128, torch.bfloat16, True)}
+       "n2k": (8, 32, 2048, 128, torch.bfloat16, True), "n1k": (16, 32, 1024, 128, torch.bfloat16, True),
+       "n2knc": (8, 32, 2048, 128, torch.bfloat16, False), "n1knc": (16, 32, 1024, 128, torch.bfloat16, False),
+       "n512": (32, 32, 512, 128, torch.bfloat16, True), "n512nc": (32, 32, 512, 128, torch.bfloat16, False),
+       "n8k": (2, 32, 8192, 128, torch.bfloat16, True)}
 dev = torch.device("cuda:0")
 
 
