@@ -54,7 +54,9 @@ static const Variant kVariants[] = {
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
-constexpr int kSmallGridVariant = 17;   // dma4-pair-2buf (128-row query blocks, two workgroups per CU)
+constexpr int kSmallGridVariant128 = 27;  // il4-pair (128-row query blocks, two workgroups per CU)
+constexpr int kSmallGridVariant64 = 21;   // dma4-pair-2buf-ldsepi
+constexpr int kSplitVariant = 17;         // dma4-pair-2buf: the kernel whose grid can carry key chunks (tfa_fwd_splitkv)
 
 struct LaunchGeom {
   int grid, block, lds;

@@ -22,7 +22,8 @@ CFG = {"cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096,
        "n2k": (8, 32, 2048, 128, torch.bfloat16, True), "n1k": (16, 32, 1024, 128, torch.bfloat16, True),
        "n2knc": (8, 32, 2048, 128, torch.bfloat16, False), "n1knc": (16, 32, 1024, 128, torch.bfloat16, False),
        "n512": (32, 32, 512, 128, torch.bfloat16, True), "n512nc": (32, 32, 512, 128, torch.bfloat16, False),
-       "n8k": (2, 32, 8192, 128, torch.bfloat16, True)}
+       "n8k": (2, 32, 8192, 128, torch.bfloat16, True),
+       "s1": (1, 8, 2048, 128, torch.bfloat16, True), "s2": (2, 16, 1024, 128, torch.bfloat16, False), "s3": (1, 32, 4096, 128, torch.bfloat16, True)}
 dev = torch.device("cuda:0")
 
 
