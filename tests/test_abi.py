@@ -128,11 +128,11 @@ def test_operator_error_behaviour_without_gpu():
 
 
 def test_variant_selection_is_introspectable_without_gpu():
-    # big grids -> the issue-interleaved kernel (lazy row reference), small grids -> 128-row-block DMA kernel
+    # big grids -> the 8-wave issue-interleaved kernel, small grids -> its 4-wave form (128-row blocks, 2 workgroups per CU)
     big = _lib.variant_for(4, 32, 32, 4096, 4096, 128, True)
     small = _lib.variant_for(4, 8, 8, 1024, 1024, 64, False, _lib.TFA_F16)
     assert _lib.variant_name(big).startswith("il8") and _lib.lazy_reference(big)
-    assert _lib.variant_name(small).startswith("dma4") and not _lib.lazy_reference(small)
+    assert _lib.variant_name(small).startswith("il4") and _lib.lazy_reference(small)
     _lib.set_variant(19)
     try:
         assert _lib.variant_for(4, 32, 32, 4096, 4096, 128, True) == 19     # a forced variant is reported as such

@@ -46,10 +46,9 @@ int pick_variant(const tfa_fwd_params* p) {
   // B4 H8 N1024 has only 128 blocks of 256 rows).
   // The issue-interleaved kernel (tfa_fwd_kernel_il.h) wins wherever the grid fills the chip (+5..11% at D=128).
   const long long blocks256 = (long long)p->B * p->H * ((p->Nq + 255) / 256);
-  // small grids: 128-row blocks (two 4-wave workgroups per CU).  D=128: the issue-interleaved 4-wave kernel
-  // (+8..9 % over the burst kernel on B1 H8 N2048 / B2 H16 N1024 / B1 H32 N4096); D=64 (VALU-bound either way): the
-  // burst kernel with the LDS epilogue (+2..4 % on BASELINE config 2).
-  if (blocks256 < 512) return p->D == 128 ? tfa::kSmallGridVariant128 : tfa::kSmallGridVariant64;
+  // small grids: 128-row blocks, two 4-wave workgroups per CU, issue-interleaved, O through the idle tile buffers
+  // (D=128: +8..15 % over the burst kernel on B1 H8 N2048 / B2 H16 N1024 / B1 H32 N4096; D=64, BASELINE config 2: +2 %)
+  if (blocks256 < 512) return tfa::kSmallGridVariant;
   // (with O leaving through LDS the 8-wave il kernel also wins on short sequences: N=512..2048, causal or not, it beats
   //  the 4-wave one by 3-5 %, tools/ab.py n512/n1k/n2k configs)
   return tfa::kDefaultVariant;

@@ -29,6 +29,8 @@ namespace tfa {
 constexpr int VF_IL = 32768;        // issue-interleaved kernel (this file)
 constexpr int VF_IL_DMASPREAD = 65536;   // issue the LDS-DMA pieces between MFMAs of part 1 instead of at the top
 constexpr int VF_IL_EPI = 262144;        // 16-bit O leaves through a separate LDS region as whole rows (16-byte coalesced stores)
+constexpr int VF_IL_EPI_INPLACE = 1048576;   // with EPI: the epilogue slices live in the (idle) tile buffers instead of a separate
+                                             // region — 64 KiB total, so two 4-wave workgroups still fit a CU
 constexpr int VF_IL_PREF = 524288;       // the next pass's K(0)/V(0)/K(1)/Q are requested BEFORE this pass's epilogue
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
                                          // so the two waves of a SIMD never sit in an LDS-DMA issue stall at the same time
@@ -623,7 +625,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       // the pass loop they would stay live across the main loop and spill)
       int qix = qi, lanex = lane;
       asm volatile("" : "+v"(qix), "+v"(lanex));
-      char* const ow = smem + 4 * TILE_BYTES + wave * (32 * D * 2);
+      constexpr bool INPLACE = (VF & VF_IL_EPI_INPLACE) != 0;
+      static_assert(!INPLACE || !PREF, "in-place epilogue slices would be overwritten by the next pass's prefetch");
+      char* const ow = smem + (INPLACE ? 0 : 4 * TILE_BYTES) + wave * (32 * D * 2);
       constexpr int CH = D / 8;                      // 16-byte chunks per row
       const int osw = (CH == 16) ? (qix & 15) : (qix & 7);
 #pragma unroll
@@ -646,7 +650,12 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
         __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, (wave_row0 + r) * (int)p.os_n * 2 + (c << 4), 0, 0);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by this wave's next epilogue only
+      if (INPLACE) {
+        // the next pass's first DMA pieces land in these buffers: every wave must have read its rows back
+        if (pass + 1 < npass) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by this wave's next epilogue only
+      }
     } else {
       T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
       auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);

@@ -51,11 +51,11 @@ static const Variant kVariants[] = {
     {"il8-pair-dmastagger (waves 4-7 issue their LDS-DMA pieces behind the first PV MFMAs instead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_DMASTAGGER, 1},
     {"il8-pair-dmaspread-epi (O leaves through a separate LDS region as whole rows, 16-byte stores)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
     {"il8-pair-dmaspread-epi-pref (+ the next pass's first tiles and Q requested before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF, 1},
+    {"il4-pair-epi (4 waves x2 workgroups per CU; O leaves through the idle tile buffers as whole rows)", 4, VF_DMA | VF_IL | VF_PAIR | VF_IL_EPI | VF_IL_EPI_INPLACE, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
-constexpr int kSmallGridVariant128 = 27;  // il4-pair (128-row query blocks, two workgroups per CU)
-constexpr int kSmallGridVariant64 = 21;   // dma4-pair-2buf-ldsepi
+constexpr int kSmallGridVariant = 32;     // il4-pair-epi (128-row query blocks, two workgroups per CU)
 constexpr int kSplitVariant = 17;         // dma4-pair-2buf: the kernel whose grid can carry key chunks (tfa_fwd_splitkv)
 
 struct LaunchGeom {
