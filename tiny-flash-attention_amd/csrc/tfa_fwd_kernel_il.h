@@ -242,6 +242,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
   const float sc = p.scale_log2;
   int nt_total = 0, n_slow = 0;
+  unsigned long long tw_wait = 0, tw_bar = 0;   // TFA_IL_TRACEWAIT debug sums
 
   const int npass = PAIR ? ((p.nmb - 1 - wi) != wi ? 2 : 1) : 1;
   constexpr bool EPI = (VF & VF_IL_EPI) != 0;
@@ -434,7 +435,20 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     // K buffer 0 is refilled with K(2) at the top of iteration 0: every wave must be done with K(0)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
+#if defined(TFA_IL_TRACEWAIT)
+    // debug build: split the end of an iteration into (memory wait) and (barrier) and sum the cycles of each
+    auto iter_end = [&]() {
+      const unsigned long long a0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const unsigned long long a1 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_barrier" ::: "memory");
+      const unsigned long long a2 = __builtin_amdgcn_s_memtime();
+      tw_wait += a1 - a0;
+      tw_bar += a2 - a1;
+    };
+#else
     auto iter_end = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#endif
 
     // ---- fast path: tile j (S in scur) -> O; S(j+1) and its row max -> snext, mnext.  One basic block. ---------
     // PAR = j & 1: K(j+1) is in K buffer PAR^1, V(j) in V buffer PAR; K(j+2) -> K buffer PAR, V(j+1) -> V buffer PAR^1.
@@ -680,6 +694,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     if (tid == 0) {
       unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
       t[0] = t_start; t[1] = t_pro; t[2] = t_loop; t[3] = t_end;
+#if defined(TFA_IL_TRACEWAIT)
+      t[1] = t_start + tw_wait; t[2] = t_start + tw_wait + tw_bar;   // debug: "prologue" = memory waits, "loop" = barrier waits of wave 0
+#endif
       t[4] = (unsigned long long)nt_total | ((unsigned long long)n_slow << 32);   // wave 0's slow-path tiles in the high half
       t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63508) | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32);   // XCC_ID | HW_ID << 32
       t[6] = __builtin_amdgcn_s_memrealtime() - rt_start;   // 100 MHz ticks over the same span as t[3] - t[0] shader cycles
