@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     const int my_row = wave_row0 + qi;
     const int wave_last_tile = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (nt - 1);
 
-    float l_run = 0.f;
+    float l4[4] = {0.f, 0.f, 0.f, 0.f};              // row sum of P, four interleaved partial sums carried across the tiles
 
     auto k_frag = [&](int kbuf, int i) -> X8 {   // fragment of QK^T MFMA i: key block i/DS, k-slot i%DS
       typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
@@ -332,12 +332,15 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     // the slow path below.  oracle/oracle.py:tiled_emulation_lazy restates this rule for the parity tests.
     float mref = -1e30f;
     auto trigger = [&](float mloc) -> bool { return __any(mloc * sc > mref + 8.f); };
+    // (mloc may be the max over only this half-wave's 32 keys of the tile: the trigger is an OR over all lanes anyway;
+    //  the re-base itself combines the two halves first so that both lanes of a row keep the same reference)
     auto rescale_if_needed = [&](float mloc) {
-      const float x = mloc * sc;
-      if (__any(x > mref + 8.f)) {
+      if (__any(mloc * sc > mref + 8.f)) {
+        const float x = pair_max(mloc) * sc;
         const float nref = fmaxf(mref, x);
         const float alpha = fast_exp2(mref - nref);
-        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l4[i] *= alpha;
         o_scale<DT>(alpha);
         mref = nref;
       }
@@ -468,7 +471,6 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       const char* vbp = vl + PAR * TILE_BYTES;
       unsigned pw[16];
       float xs[32];
-      float lsum[4] = {0.f, 0.f, 0.f, 0.f};
       X8 kf[N1], vf[N2];
 #pragma unroll
       for (int i = 0; i < PFK; ++i) kf[i] = k_frag(KB, i);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
           } else {
             if (sa_e == g) st_fma(e, scur, msc, xs);
             if (sb_e == g) st_exp(e, xs);
-            if (sc_e == g) st_sum(e, xs, lsum, pw);
+            if (sc_e == g) st_sum(e, xs, l4, pw);
           }
         }
       };
@@ -545,8 +547,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
           }
         __builtin_amdgcn_sched_barrier(0);
       }
-      l_run += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
-      mnext = (AB & ILAB_NOMAX) ? snext[0][0] * 1e-30f : pair_max(mx);
+      mnext = (AB & ILAB_NOMAX) ? snext[0][0] * 1e-30f : mx;   // this half-wave's 32 keys only (see rescale_if_needed)
       if (AB & ILAB_NOBARRIER) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else iter_end();
     };
@@ -561,10 +562,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       const char* vbp = vl + par * TILE_BYTES;
       unsigned pw[16];
       float ev_hold = 0.f;
-      float lsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 32; ++e) soft_elem(e, scur, msc, lsum, pw, ev_hold);
-      l_run += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+      for (int e = 0; e < 32; ++e) soft_elem(e, scur, msc, l4, pw, ev_hold);
 #pragma unroll
       for (int i = 0; i < N2; ++i) o_mfma_d<T>(i % DT, v_frag(vbp, i), p_frag(pw, i / DT));
       if (j + 1 < nact) qk_burst(par ^ 1, j + 1, snext, mnext);
@@ -606,7 +605,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     // every wave is past the last tile's barrier: the K/V buffers and qf are free -> ask for the next pass's first tiles
     // and Q now, so that their latency hides behind the normalisation and the stores below
     if (PREF && pass + 1 < npass) issue_prologue(block_of(pass + 1));
-    const float l_tot = pair_sum(l_run);
+    const float l_tot = pair_sum((l4[0] + l4[1]) + (l4[2] + l4[3]));
     const bool empty = !(l_tot > 0.f);
     const float inv = empty ? 1.f : 1.f / l_tot;
     if (p.lse != nullptr && hi == 0 && my_row < p.Nq) {
