@@ -24,6 +24,10 @@
  *                        flash_attention_c/csrc/attn.cpp:171-203     (strided params, causal offset)
  *   tfa_strerror      <- CUDA_ERROR_CHECK / TORCH_CHECK text
  *                        flash_attention_cutlass/include/attention_api.cuh:12-29
+ *   tfa_merge, tfa_fwd_splitkv (partial results over key chunks + merge)
+ *                     <- the v1 block-merge rule  flash_attention_py/tiny_flash_attn.py:63-68, README_zh.md:104-125
+ *   tfa_bwd           <- no reference entry: the reference only SAVES softmax_lse for a backward
+ *                        flash_attention_cutlass/csrc/flash_attention.cu:353-354, 614-623
  *
  * Semantics (identical to the reference; see oracle/ for the CPU restatement):
  *   S[i,j]  = softmax_scale * sum_d q[i,d] k[j,d]            (16-bit products, fp32 accumulate)
@@ -34,6 +38,9 @@
  *   O -> rounded to the input dtype (RNE), or left fp32 when out_dtype == TFA_F32
  *   LSE_i   = m_i + ln(l_i)   (natural log, scale included)  (flash_attention.cu:623)
  *   empty row (no visible key): O = 0, LSE = +inf            (flash_attention.cu:620-623)
+ * Rounding points: the kernels that serve most shapes ("il" variants, see tfa_fwd_variant) form P against a
+ * per-row reference exponent that trails the running max by at most 2^8 instead of the exact running max
+ * (same O and LSE mathematically, P <= 2^8) — within the same tolerances as the exact rule.
  *
  * Error convention: every entry point returns 0 on success, a negative tfa_status on a
  * rejected argument (nothing was launched), or a positive hipError_t when the HIP runtime
@@ -49,7 +56,7 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 101 /* 0.1.0 */
+#define TFA_VERSION 101 /* 0.1.1: + split-KV fields of tfa_fwd_params, tfa_merge, tfa_fwd_splitkv, tfa_bwd */
 
 /* element types */
 enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1, TFA_F32 = 2 /* output only */ };
