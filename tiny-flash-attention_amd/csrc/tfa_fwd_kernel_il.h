@@ -32,7 +32,7 @@ namespace tfa {
 static __device__ __forceinline__ void lds_dma16_m0(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, int voffset) {
   asm volatile(
       "s_mov_b32 m0, %0\n\t"
-      "s_nop 4\n\t"
+      "s_nop 0\n\t"                                     // SALU write of M0 -> LDS-DMA reads it: 1 wait state
       "buffer_load_dwordx4 %1, %2, 0 offen lds"
       :
       : "s"(lds_addr), "v"(voffset), "s"(rs)
