@@ -179,12 +179,14 @@ def test_il_kernels_leave_the_pinned_accumulator_registers_alone():
         if m:
             cur = m.group(1)
             continue
-        if not cur or "fwd_kernel_il" not in cur:
+        if not cur or ("fwd_kernel_il" not in cur and "bwd_kernel" not in cur):
             continue
         text = line.split("//")[0]
-        # the il kernels' LDS-DMA helper leaves M0 set (no save/restore): nothing else in them may read or write M0
+        # the il and backward kernels' LDS-DMA helper leaves M0 set (no save/restore): nothing else in them may touch M0
         if re.search(r"\bm0\b", text) and not text.split()[0:2] == ["s_mov_b32", "m0,"]:
             bad.append(f"{cur[:60]}: M0 used outside the LDS-DMA helper: {text.strip()}")
+        if "fwd_kernel_il" not in cur:
+            continue
         regs = [int(x) for x in re.findall(r"\bv(\d+)\b", text)]
         regs += [int(hi) for _, hi in re.findall(r"v\[(\d+):(\d+)\]", text)]
         if not regs or max(regs) < 192:

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
       auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000);
 #pragma unroll
       for (int i = 0; i < PPW; ++i)
-        lds_dma16(rs, lds_base + (stage * NIMG + img) * TILE_BYTES + (wave * PPW + i) * 1024, src[img][i] + jt * tile_stride[img]);
+        lds_dma16_m0(rs, lds_base + (stage * NIMG + img) * TILE_BYTES + (wave * PPW + i) * 1024, src[img][i] + jt * tile_stride[img]);
     }
   };
 

@@ -36,6 +36,19 @@ static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsi
       : "memory");
 }
 
+// LDS-DMA without saving/restoring M0 around it (2 SALU less per piece in the hot loop).  Safe only because nothing else
+// in the kernels that call it (fwd_kernel_il, bwd_kernel) uses M0 (hipcc emits no M0 user here: LDS instructions need none on gfx9+, SGPR spills use immediate
+// lane indices); tests/test_abi.py disassembles the library and fails if that ever changes.
+static __device__ __forceinline__ void lds_dma16_m0(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, int voffset) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"                                     // SALU write of M0 -> LDS-DMA reads it: 1 wait state
+      "buffer_load_dwordx4 %1, %2, 0 offen lds"
+      :
+      : "s"(lds_addr), "v"(voffset), "s"(rs)
+      : "memory", "m0");
+}
+
 constexpr int VF_PERSIST = 2048;   // launch one workgroup per CU and walk the work items (else one item per workgroup)
 constexpr int VF_2BUF = 4096;      // two LDS tile buffers (64 KiB at D=128): two 4-wave workgroups fit one CU
 constexpr int VF_LDSEPI = 16384;   // epilogue: transpose O through LDS and store whole rows (16-byte coalesced stores)

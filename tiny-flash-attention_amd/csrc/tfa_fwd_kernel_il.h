@@ -26,19 +26,6 @@
 
 namespace tfa {
 
-// LDS-DMA without saving/restoring M0 around it (2 SALU less per piece in the hot loop).  Safe only because nothing else
-// in these kernels uses M0 (hipcc emits no M0 user here: LDS instructions need none on gfx9+, SGPR spills use immediate
-// lane indices); tests/test_abi.py disassembles the library and fails if that ever changes.
-static __device__ __forceinline__ void lds_dma16_m0(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, int voffset) {
-  asm volatile(
-      "s_mov_b32 m0, %0\n\t"
-      "s_nop 0\n\t"                                     // SALU write of M0 -> LDS-DMA reads it: 1 wait state
-      "buffer_load_dwordx4 %1, %2, 0 offen lds"
-      :
-      : "s"(lds_addr), "v"(voffset), "s"(rs)
-      : "memory", "m0");
-}
-
 constexpr int VF_IL = 32768;        // issue-interleaved kernel (this file)
 constexpr int VF_IL_DMASPREAD = 65536;   // issue the LDS-DMA pieces between MFMAs of part 1 instead of at the top
 constexpr int VF_IL_EPI = 262144;        // 16-bit O leaves through a separate LDS region as whole rows (16-byte coalesced stores)
