@@ -1,6 +1,6 @@
 """A/B of kernel variants on the GPU box: quick correctness of each variant against the oracle on a
 small problem, then interleaved timing rounds on the BASELINE shapes.
-usage: python tools/ab.py [--variants 1,4,5] [--cfgs cfg3,cfg3nc] [--rounds 3]"""
+usage: python tests/tools/ab.py [--variants 1,4,5] [--cfgs cfg3,cfg3nc] [--rounds 3]"""
 import argparse
 import ctypes as C
 import json
@@ -10,7 +10,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tiny_flash_attention_amd import _lib, ops  # noqa: E402
 from oracle import oracle as O  # noqa: E402

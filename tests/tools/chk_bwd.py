@@ -1,7 +1,7 @@
-"""Quick check of tfa_bwd against the fp64 autograd oracle.  usage: python tools/chk_bwd.py"""
+"""Quick check of tfa_bwd against the fp64 autograd oracle.  usage: python tests/tools/chk_bwd.py"""
 import math, os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tiny_flash_attention_amd import _lib, ops
 from oracle import oracle as O

@@ -1,9 +1,9 @@
 """Randomised sweep of the backward pass: random (B,H,Hk,Nq,Nk,D,dtype,causal,scale,layout) against the fp64 autograd
 oracle with the rigorous 16-bit-rounding bounds of tests/test_bwd_gpu.py (B1 on fp32 gradients, B3 on 16-bit ones).
-usage: python tools/fuzz_bwd.py [--cases 100] [--seed 0]"""
+usage: python tests/tools/fuzz_bwd.py [--cases 100] [--seed 0]"""
 import argparse, math, os, random, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tiny_flash_attention_amd import ops
 from oracle import oracle as O

@@ -1,11 +1,11 @@
 """Randomised parity sweep: random (B,H,Hk,Nq,Nk,D,dtype,causal,scale,layout) through chosen kernel variants against the
 fp64 oracle (16-bit bar 1e-2 scaled with |O|; rigorous fp32-out bound 2^-8 A / 2^-11 A from rounding P; LSE and its +inf
 pattern) and the matching same-rounding-points emulation (rtol 1e-3 outlier fraction, judged only on large cases).
-Round 1: 620 cases over variants {auto, 17, 27, 30, 31, 32}: no violation of the rigorous bounds (tools/fuzz_bwd.py: 150 backward cases, none).
-usage: python tools/fuzz_parity.py [--cases 150] [--variants -1,27,30] [--seed 0]"""
+Round 1: 620 cases over variants {auto, 17, 27, 30, 31, 32}: no violation of the rigorous bounds (tests/tools/fuzz_bwd.py: 150 backward cases, none).
+usage: python tests/tools/fuzz_parity.py [--cases 150] [--variants -1,27,30] [--seed 0]"""
 import argparse, math, os, random, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tiny_flash_attention_amd import _lib, ops
 from oracle import oracle as O

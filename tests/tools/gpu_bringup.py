@@ -9,7 +9,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import tiny_flash_attention_amd as tfa  # noqa: E402
 from tiny_flash_attention_amd import _lib, ops  # noqa: E402

@@ -40,7 +40,7 @@ int num_cus() {
 int pick_variant(const tfa_fwd_params* p) {
   if (g_variant >= 0) return g_variant;
   if (!p) return tfa::kDefaultVariant;
-  // Measured on MI355X (tools/ab.py, profiles/): 256-row query blocks (8 waves) are fastest when there
+  // Measured on MI355X (tests/tools/ab.py, profiles/): 256-row query blocks (8 waves) are fastest when there
   // are enough of them to fill 256 CUs and no causal diagonal; 128-row blocks (two 4-wave workgroups per
   // CU) waste less of the causal diagonal and fill the chip on small problems (BASELINE config 2:
   // B4 H8 N1024 has only 128 blocks of 256 rows).
@@ -50,7 +50,7 @@ int pick_variant(const tfa_fwd_params* p) {
   // (D=128: +8..15 % over the burst kernel on B1 H8 N2048 / B2 H16 N1024 / B1 H32 N4096; D=64, BASELINE config 2: +2 %)
   if (blocks256 < 512) return tfa::kSmallGridVariant;
   // (with O leaving through LDS the 8-wave il kernel also wins on short sequences: N=512..2048, causal or not, it beats
-  //  the 4-wave one by 3-5 %, tools/ab.py n512/n1k/n2k configs)
+  //  the 4-wave one by 3-5 %, tests/tools/ab.py n512/n1k/n2k configs)
   return tfa::kDefaultVariant;
 }
 

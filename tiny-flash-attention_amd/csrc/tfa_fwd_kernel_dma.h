@@ -52,7 +52,7 @@ static __device__ __forceinline__ void lds_dma16_m0(__amdgpu_buffer_rsrc_t rs, u
 constexpr int VF_PERSIST = 2048;   // launch one workgroup per CU and walk the work items (else one item per workgroup)
 constexpr int VF_2BUF = 4096;      // two LDS tile buffers (64 KiB at D=128): two 4-wave workgroups fit one CU
 constexpr int VF_LDSEPI = 16384;   // epilogue: transpose O through LDS and store whole rows (16-byte coalesced stores)
-constexpr int VF_PRIO = 1024;   // s_setprio(1) around the MFMA clusters (experiment, tools/ab.py)
+constexpr int VF_PRIO = 1024;   // s_setprio(1) around the MFMA clusters (experiment, tests/tools/ab.py)
 
 // The kernel walks a STREAM of query blocks: workgroup g takes work items g, g+G, g+2G, ... (G =
 // gridDim.x; a causal work item is the pair {heavy block nmb-1-i, light block i}, so every item costs
