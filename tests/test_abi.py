@@ -235,3 +235,32 @@ def test_bwd_descriptor_validation_without_gpu():
     assert L.tfa_bwd_work(C.byref(p), C.byref(f), C.byref(b)) == 0
     assert f.value == pytest.approx(2.5 * 5.498e11, rel=1e-3)
     assert b.value == pytest.approx(8 * 4 * 32 * 4096 * 128 * 2 + 4 * 4 * 32 * 4096, rel=1e-6)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/tfa.h must be usable from C (the boundary is a C ABI): compile a C translation unit that fills the
+    descriptors and references every entry point, with gcc -std=c99 -Wall -Werror, and link it against the library."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not present")
+    calls = "\n".join(f"  (void)&{name};" for name in header_symbols())
+    src = tmp_path / "use_tfa.c"
+    src.write_text(
+        '#include "tfa.h"\n#include <string.h>\n'
+        "int main(void) {\n"
+        "  tfa_fwd_params p; tfa_bwd_params b;\n"
+        "  memset(&p, 0, sizeof p); memset(&b, 0, sizeof b);\n"
+        "  p.B = 1; p.H = 1; p.Hk = 1; p.Nq = 64; p.Nk = 64; p.D = 64; p.softmax_scale = 0.125f; p.dtype = TFA_BF16; p.out_dtype = TFA_BF16;\n"
+        f"{calls}\n"
+        "  return tfa_fwd_plan(&p, 0, 0, 0) == TFA_ERR_NULL && tfa_version() == TFA_VERSION ? 0 : 1;\n"
+        "}\n")
+    exe = tmp_path / "use_tfa"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe),
+                        f"-L{libdir}", "-ltfa_hip", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[:2000]
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, (run.returncode, run.stderr[:500])
