@@ -6,7 +6,8 @@
  * Everything here is `extern "C"`, plain pointers and sizes; no torch types.
  * Pointers are DEVICE pointers (HBM) unless stated otherwise.  The library never
  * allocates or frees device memory and keeps no state between calls except the
- * debug knob tfa_set_variant().
+ * PER-THREAD debug knobs tfa_set_variant() / tfa_debug_set_trace() (thread-local: a thread
+ * that forces a variant does not change what other threads' calls run).
  *
  * Reference interfaces each entry point replaces (paths relative to the reference repo):
  *
@@ -56,7 +57,7 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 101 /* 0.1.1: + split-KV fields of tfa_fwd_params, tfa_merge, tfa_fwd_splitkv, tfa_bwd */
+#define TFA_VERSION 102 /* 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
 
 /* element types */
 enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1, TFA_F32 = 2 /* output only */ };
@@ -67,7 +68,7 @@ enum tfa_status {
   TFA_ERR_DTYPE = -2,         /* dtype not in {F16,BF16}; out_dtype not in {dtype,F32} */
   TFA_ERR_HEAD_DIM = -3,      /* D not in {64,128} */
   TFA_ERR_SHAPE = -4,         /* B,H,Hk,Nq,Nk <= 0 or H % Hk != 0 */
-  TFA_ERR_STRIDE = -5,        /* a stride is negative, not 16-byte aligned, or a slice exceeds 4 GiB */
+  TFA_ERR_STRIDE = -5,        /* a stride is negative, not 16-byte aligned, or a (b,h) slice reaches 2 GiB */
   TFA_ERR_ALIGN = -6,         /* a base pointer is not 16-byte aligned */
   TFA_ERR_VARIANT = -7,       /* unknown kernel variant */
   TFA_ERR_SCALE = -8          /* softmax_scale is not finite or is <= 0 */
@@ -203,12 +204,16 @@ int tfa_bwd_work(const tfa_bwd_params* p, double* flops, double* bytes);
 /* Time `iters` back-to-back tfa_bwd calls with HIP events on `stream` (after `warmup` untimed ones). */
 int tfa_bwd_time(const tfa_bwd_params* p, int warmup, int iters, void* stream, float* avg_ms);
 
-/* Kernel-variant selector for A/B measurement and bring-up.  -1 = automatic (default).
+/* Kernel-variant selector for A/B measurement and bring-up (state of the CALLING THREAD).  -1 = automatic (default).
  * tfa_num_variants() variants exist; tfa_variant_name(i) describes variant i. */
 int tfa_set_variant(int variant);
 int tfa_get_variant(void);
 int tfa_num_variants(void);
 const char* tfa_variant_name(int variant);
+/* 1 if variant i is compiled into this build, else 0.  The product build carries the dispatched kernels only; the
+ * other entries of the table are A/B arms built with -DTFA_EXPERIMENTAL (make EXPERIMENTAL=1) and are rejected
+ * with TFA_ERR_VARIANT otherwise. */
+int tfa_variant_available(int variant);
 
 /* Debug/profiling: when dev_buf != NULL every workgroup of subsequent launches writes 8 x uint64
  * {t_start, t_after_prologue, t_after_loop, t_end (shader cycles, s_memtime), n_kv_tiles (low 32 bits),

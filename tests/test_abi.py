@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"include/tfa.h declares {n} but libtfa_hip.so does not export it"
     assert sorted(_lib.SYMBOLS) == names
-    assert L.tfa_version() == 101
+    assert L.tfa_version() == 102
 
 
 def _params(B=2, H=4, Hk=4, Nq=128, Nk=128, D=128, dtype=_lib.TFA_BF16, out_dtype=None, scale=0.1, base=0x10000):
@@ -51,28 +51,45 @@ def plan(p):
 
 
 def test_plan_geometry():
-    _lib.set_variant(1)
-    st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
-    assert st == 0 and block == 512 and grid == 4 * 32 * (4096 // 256) and lds == 4 * 64 * 128 * 2
-    _lib.set_variant(2)
-    st, grid, block, lds = plan(_params(B=4, H=8, Hk=8, Nq=1000, Nk=1000, D=64, dtype=_lib.TFA_F16))
-    assert st == 0 and block == 256 and grid == 4 * 8 * 8 and lds == 4 * 64 * 64 * 2
-    _lib.set_variant(11)  # LDS-DMA kernel: three K and three V tile buffers
-    st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
-    assert st == 0 and block == 512 and grid == 4 * 32 * 8 and lds == 6 * 64 * 128 * 2
-    _lib.set_variant(15)  # persistent: one workgroup per CU walks the 1024 work items
-    st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
-    assert st == 0 and block == 512 and grid == 256
+    big = dict(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128)
+    _lib.set_variant(17)  # LDS-DMA kernel, two K and two V tile buffers, 128-row blocks paired (the split-KV kernel)
+    st, grid, block, lds = plan(_params(**big))
+    assert st == 0 and block == 256 and grid == 4 * 32 * 16 and lds == 4 * 64 * 128 * 2
     _lib.set_variant(-1)  # automatic: headline shape -> issue-interleaved kernel, 256-row blocks paired, 2 K + 2 V buffers
-    st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))   # + one 32-row epilogue slice per wave
+    st, grid, block, lds = plan(_params(**big))   # + one 32-row epilogue slice per wave
     assert st == 0 and block == 512 and grid == 4 * 32 * 8 and lds == 4 * 64 * 128 * 2 + 8 * 32 * 128 * 2
     # automatic, small grid (BASELINE config 2) -> 128-row blocks, two 4-wave workgroups per CU
     st, grid, block, lds = plan(_params(B=4, H=8, Hk=8, Nq=1024, Nk=1024, D=64, dtype=_lib.TFA_F16))
     assert st == 0 and block == 256 and grid == 4 * 8 * 4 and lds == 4 * 64 * 64 * 2
-    _lib.set_variant(4)   # causal blocks paired: ceil(16/2) work items per head
-    st, grid, block, lds = plan(_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128))
-    assert st == 0 and block == 512 and grid == 4 * 32 * 8
+    if _lib.variant_available(1):   # A/B arms (make EXPERIMENTAL=1)
+        _lib.set_variant(1)
+        st, grid, block, lds = plan(_params(**big))
+        assert st == 0 and block == 512 and grid == 4 * 32 * (4096 // 256) and lds == 4 * 64 * 128 * 2
+        _lib.set_variant(2)
+        st, grid, block, lds = plan(_params(B=4, H=8, Hk=8, Nq=1000, Nk=1000, D=64, dtype=_lib.TFA_F16))
+        assert st == 0 and block == 256 and grid == 4 * 8 * 8 and lds == 4 * 64 * 64 * 2
+        _lib.set_variant(11)  # LDS-DMA kernel: three K and three V tile buffers
+        st, grid, block, lds = plan(_params(**big))
+        assert st == 0 and block == 512 and grid == 4 * 32 * 8 and lds == 6 * 64 * 128 * 2
+        _lib.set_variant(15)  # persistent: one workgroup per CU walks the 1024 work items
+        st, grid, block, lds = plan(_params(**big))
+        assert st == 0 and block == 512 and grid == 256
+        _lib.set_variant(4)   # causal blocks paired: ceil(16/2) work items per head
+        st, grid, block, lds = plan(_params(**big))
+        assert st == 0 and block == 512 and grid == 4 * 32 * 8
     _lib.set_variant(-1)
+
+
+def test_product_build_rejects_ab_arms():
+    # the product library carries the dispatched kernels only (tfa_launch.h); the other table entries answer TFA_ERR_VARIANT
+    L = _lib.lib()
+    avail = [v for v in range(_lib.num_variants()) if _lib.variant_available(v)]
+    for v in (17, 30, 32):
+        assert v in avail
+    for v in range(_lib.num_variants()):
+        if v not in avail:
+            assert L.tfa_set_variant(v) == -7
+    assert _lib.get_variant() == -1
 
 
 def test_rejects_bad_descriptors():
@@ -133,9 +150,9 @@ def test_variant_selection_is_introspectable_without_gpu():
     small = _lib.variant_for(4, 8, 8, 1024, 1024, 64, False, _lib.TFA_F16)
     assert _lib.variant_name(big).startswith("il8") and _lib.lazy_reference(big)
     assert _lib.variant_name(small).startswith("il4") and _lib.lazy_reference(small)
-    _lib.set_variant(19)
+    _lib.set_variant(17)
     try:
-        assert _lib.variant_for(4, 32, 32, 4096, 4096, 128, True) == 19     # a forced variant is reported as such
+        assert _lib.variant_for(4, 32, 32, 4096, 4096, 128, True) == 17     # a forced variant is reported as such
     finally:
         _lib.set_variant(-1)
     with pytest.raises(_lib.TfaError):

@@ -46,6 +46,14 @@ def tfa():
     _lib.set_variant(-1)
 
 
+def _need_variant(variant):
+    """The product build carries the dispatched kernels only; A/B arms need `make EXPERIMENTAL=1` (tfa_launch.h)."""
+    from tiny_flash_attention_amd import _lib
+
+    if variant >= 0 and not _lib.variant_available(variant):
+        pytest.skip(f"kernel variant {variant} is an A/B arm: not in the product build (make EXPERIMENTAL=1)")
+
+
 def check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype, var=None):
     """q,k,v: CPU tensors (B,H,Nq,D)/(B,Hk,Nk,D) of `dtype`; out*/lse: kernel results.  `var`: the kernel variant
     that produced them when q,k,v are only a slice of the problem the kernel saw (default: ask the library)."""
@@ -114,8 +122,7 @@ SHAPES = [
 def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
     from tiny_flash_attention_amd import _lib
 
-    if variant >= _lib.num_variants():
-        pytest.skip("variant not built")
+    _need_variant(variant)
     _lib.set_variant(variant)
     try:
         run_case(tfa, oracle, dev, dtype, B, H, N, D, causal)
@@ -131,6 +138,7 @@ def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
     # (flash_attention_c/csrc/attn.cpp:121-124); (384,128,causal) has 256 EMPTY rows -> O=0, LSE=+inf
     from tiny_flash_attention_amd import _lib
 
+    _need_variant(variant)
     _lib.set_variant(variant)
     try:
         run_case(tfa, oracle, dev, torch.bfloat16, 1, 4, Nq, 128, causal, Hk=2, Nk=Nk, seed=7)
@@ -232,6 +240,7 @@ def test_late_max_jump_spike(tfa, oracle, dev, variant):
     for (row, key, gain) in ((5, 700, 6.0), (300, 900, 9.0), (1000, 64, 4.0), (37, 1023, 12.0)):
         k[0, :, key] = (q[0, :, row].float() * gain).to(torch.bfloat16)
     sc = 1.0 / math.sqrt(128)
+    _need_variant(variant)
     _lib.set_variant(variant)
     try:
         for causal in (False, True):
@@ -330,6 +339,7 @@ def test_strided_bnhd_matches_bhnd(tfa, oracle, dev, variant):
 
     q, k, v = oracle.make_inputs(2, 8, 384, 128, torch.bfloat16, seed=5, Hk=2)
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    _need_variant(variant)
     _lib.set_variant(variant)
     try:
         o_bhnd, l_bhnd = ops.flash_attn_fwd(qd, kd, vd, True, 0.09)

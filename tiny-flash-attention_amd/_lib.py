@@ -22,6 +22,7 @@ SYMBOLS = (
     "tfa_get_variant",
     "tfa_num_variants",
     "tfa_variant_name",
+    "tfa_variant_available",
     "tfa_fwd_work",
     "tfa_debug_set_trace",
     "tfa_merge",
@@ -140,6 +141,8 @@ def lib():
     L.tfa_num_variants.restype = C.c_int
     L.tfa_variant_name.restype = C.c_char_p
     L.tfa_variant_name.argtypes = [C.c_int]
+    L.tfa_variant_available.restype = C.c_int
+    L.tfa_variant_available.argtypes = [C.c_int]
     L.tfa_debug_set_trace.restype = C.c_int
     L.tfa_debug_set_trace.argtypes = [C.c_void_p]
     L.tfa_fwd_splitkv.restype = C.c_int
@@ -182,6 +185,12 @@ def get_variant():
 
 def num_variants():
     return lib().tfa_num_variants()
+
+
+def variant_available(v):
+    """True when kernel variant `v` is compiled into the loaded library (the product build carries only the
+    dispatched kernels; A/B arms need `make EXPERIMENTAL=1`)."""
+    return bool(lib().tfa_variant_available(int(v)))
 
 
 def variant_name(v):

@@ -21,21 +21,12 @@ template <> hipError_t launch_fwd<_Float16, 128>(const KArgs&, bool, bool, int, 
 
 namespace {
 
-int g_variant = -1;   // -1 = automatic
-unsigned long long* g_trace = nullptr;   // debug: per-workgroup cycle stamps (tfa_debug_set_trace)
+// Debug knobs (tfa_set_variant, tfa_debug_set_trace) are PER THREAD: a thread that forces a variant or a trace buffer
+// for an A/B measurement does not change what any other thread's calls run.  Nothing else in the library is mutable.
+thread_local int g_variant = -1;   // -1 = automatic
+thread_local unsigned long long* g_trace = nullptr;   // per-workgroup cycle stamps (tfa_debug_set_trace)
 
-int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      n = prop.multiProcessorCount;
-    else
-      n = 256;   // MI355X; also the answer when no device is visible (dry-run planning on a CPU box)
-  }
-  return n;
-}
+int num_cus() { return tfa::num_cus_current_device(); }
 
 int pick_variant(const tfa_fwd_params* p) {
   if (g_variant >= 0) return g_variant;
@@ -74,7 +65,7 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   if (p->H % p->Hk != 0) return TFA_ERR_SHAPE;
   if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
   const bool ablate = (variant >= 100 && variant < 100 + 512) || (variant >= 700 && variant < 716) || (variant >= 1000 && variant < 2256);   // timing-only ablations (debug)
-  if (!ablate && (variant < 0 || variant >= tfa::kNumVariants)) return TFA_ERR_VARIANT;
+  if (!ablate && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
   const int esz = 2, osz = (p->out_dtype == TFA_F32) ? 4 : 2;
   const int64_t* st[4] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride};
   for (int t = 0; t < 4; ++t) {
@@ -287,12 +278,14 @@ int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, f
 
 int tfa_set_variant(int variant) {
   if (variant < -1 || (variant >= tfa::kNumVariants && (variant < 100 || variant >= 2256 || (variant >= 716 && variant < 1000) || (variant >= 612 && variant < 700)))) return TFA_ERR_VARIANT;
+  if (variant >= 0 && variant < tfa::kNumVariants && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
   g_variant = variant;
   return TFA_OK;
 }
 int tfa_get_variant(void) { return g_variant; }
 int tfa_debug_set_trace(void* dev_buf) { g_trace = reinterpret_cast<unsigned long long*>(dev_buf); return TFA_OK; }
 int tfa_num_variants(void) { return tfa::kNumVariants; }
+int tfa_variant_available(int variant) { return tfa::variant_built(variant) ? 1 : 0; }
 const char* tfa_variant_name(int variant) {
   if (variant < 0 || variant >= tfa::kNumVariants) return "auto";
   return tfa::kVariants[variant].name;

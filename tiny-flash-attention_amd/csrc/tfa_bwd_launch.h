@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "tfa_bwd_kernel.h"
+#include "tfa_host_util.h"
 
 namespace tfa {
 template <typename T, int D>

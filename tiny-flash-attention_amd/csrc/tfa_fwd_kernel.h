@@ -145,6 +145,9 @@ constexpr int VF_W64 = 8192;     // 64 rows per wave, AGPR-pinned O (tfa_fwd_ker
 constexpr int VF_SWP = 128;      // software-pipelined DMA kernel (tfa_fwd_kernel_swp.h)
 constexpr int VF_DMA = 64;       // LDS-DMA staging kernel (tfa_fwd_kernel_dma.h)
 constexpr int VF_PP = 32;        // ping-pong schedule (tfa_fwd_kernel_pp.h)
+constexpr int VF_VPRE_SHIFT = 8;      // ping-pong kernel, bits 8..10: number of 32-wide d-tiles whose V fragments are read in the first half
+constexpr int VF_NOPQK_SHIFT = 16;    // ping-pong kernel, bits 16..20: 0 = off, n = "s_nop n-1" after every QK^T MFMA
+constexpr int VF_NOPPV_SHIFT = 21;    // ping-pong kernel, bits 21..25: same after every PV MFMA
 constexpr int VF_VPRE = 16;      // issue all V fragment reads before the softmax, PV runs from registers
 
 // Ablation bits (timing experiments only — results are WRONG with any bit set; never dispatched by tfa_fwd)

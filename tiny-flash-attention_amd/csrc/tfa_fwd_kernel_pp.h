@@ -27,11 +27,9 @@
 
 namespace tfa {
 
-constexpr int VF_VPRE_SHIFT = 8;   // bits 8..10: number of 32-wide d-tiles whose V fragments are read in the first half
 // Issue-port padding (tools/probe_issue.hip): a wave streaming back-to-back MFMAs re-arms the SIMD's VALU issue port
 // the moment it frees, so VALU work of the OTHER wave on that SIMD never gets in; an s_nop behind each MFMA leaves the gap.
-constexpr int VF_NOPQK_SHIFT = 16; // bits 16..20: 0 = off, n = "s_nop n-1" after every QK^T MFMA
-constexpr int VF_NOPPV_SHIFT = 21; // bits 21..25: same after every PV MFMA
+// (VF_NOPQK_SHIFT / VF_NOPPV_SHIFT, tfa_fwd_kernel.h: "s_nop n-1" after every QK^T / PV MFMA)
 template <int N, typename ACC> static __device__ __forceinline__ void issue_gap(ACC& acc) {
   if constexpr (N > 0) asm volatile("s_nop %1" : "+v"(acc) : "n"(N - 1));
 }

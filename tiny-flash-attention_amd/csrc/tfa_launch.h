@@ -1,12 +1,18 @@
 // tfa_launch.h — host-side dispatch table shared by the per-(dtype, head-dim) instantiation units.
 #pragma once
+// The product library dispatches four kernels only (kDefaultVariant, kSmallGridVariant, kSplitVariant below); every
+// other entry of kVariants is a measured dead end or an A/B arm kept for the record and is compiled only with
+// -DTFA_EXPERIMENTAL (make EXPERIMENTAL=1).  Without the flag those variant numbers are rejected (TFA_ERR_VARIANT).
 #include <hip/hip_runtime.h>
+#include "tfa_host_util.h"
 #include "tfa_fwd_kernel.h"
-#include "tfa_fwd_kernel_pp.h"
 #include "tfa_fwd_kernel_dma.h"
+#include "tfa_fwd_kernel_il.h"
+#if defined(TFA_EXPERIMENTAL)
+#include "tfa_fwd_kernel_pp.h"
 #include "tfa_fwd_kernel_swp.h"
 #include "tfa_fwd_kernel_w64.h"
-#include "tfa_fwd_kernel_il.h"
+#endif
 
 namespace tfa {
 
@@ -64,6 +70,30 @@ struct LaunchGeom {
 
 template <typename T, int D>
 hipError_t launch_fwd(const KArgs& a, bool causal, bool f32out, int variant, hipStream_t stream, LaunchGeom* geom, bool dry);
+
+// variants compiled into this build
+static inline bool variant_built(int variant) {
+  if (variant < 0 || variant >= kNumVariants) return false;
+#if defined(TFA_EXPERIMENTAL)
+  return true;
+#else
+  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant;
+#endif
+}
+
+// common tail of every launcher: report the geometry, opt in to the dynamic LDS size on this device, launch, and return
+// THIS launch's status (a sticky error left behind by unrelated earlier HIP calls is cleared first).
+template <typename Kern>
+static inline hipError_t launch_common(Kern kern, std::atomic<unsigned long long>& mask, int grid, int block, int lds,
+                                       const KArgs& a, hipStream_t stream, LaunchGeom* geom, bool dry) {
+  if (geom) { geom->grid = grid; geom->block = block; geom->lds = lds; }
+  if (dry) return hipSuccess;
+  hipError_t e = set_dyn_lds_once(mask, reinterpret_cast<const void*>(kern), lds);
+  if (e != hipSuccess) return e;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, a);
+  return hipGetLastError();
+}
 
 static inline int block_m_of(int variant) { return kVariants[variant].nw * 32 * kVariants[variant].rb; }
 static inline bool uses_dma(int variant) { return (kVariants[variant].vf & VF_DMA) != 0; }

@@ -58,6 +58,7 @@ extern "C" int tfa_merge(const float* o_parts, const float* lse_parts, int npart
   if (threads / 256 >= (long long)0x7fffffff) return TFA_ERR_SHAPE;
   const int grid = (int)((threads + 255) / 256);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  (void)hipGetLastError();   // report THIS launch's status, not a stale sticky error
   if (out_dtype == TFA_BF16)
     hipLaunchKernelGGL(merge_kernel<__bf16>, dim3(grid), dim3(256), 0, s, o_parts, lse_parts, nparts, (long long)rows, D, (long long)o_part_stride,
                        (long long)lse_part_stride, reinterpret_cast<__bf16*>(out), lse_out);

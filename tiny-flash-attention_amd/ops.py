@@ -62,6 +62,15 @@ def flash_attn_fwd(q, k, v, is_causal=False, softmax_scale=None, *, layout="bhnd
 
     if out is None:
         out = torch.empty(q.shape, dtype=torch.float32 if out_f32 else q.dtype, device=q.device)
+    else:   # a caller-owned result buffer: the kernel writes q.shape elements at out's strides — check before launching
+        if not isinstance(out, torch.Tensor) or out.shape != q.shape:
+            raise RuntimeError(f"out must be a tensor shaped like q {tuple(q.shape)}")
+        if out.device != q.device:
+            raise RuntimeError("out must be on q's device")
+        if out.dtype not in (q.dtype, torch.float32):
+            raise RuntimeError(f"out must be {q.dtype} or float32 (got {out.dtype})")
+        if out.stride(3) != 1:
+            raise RuntimeError("out must have unit stride along the head dimension")
     lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device) if return_lse else None
 
     p = _lib.TfaFwdParams()
@@ -204,6 +213,12 @@ def flash_attn_bwd(q, k, v, out, lse, dout, is_causal=False, softmax_scale=None,
     D = q.shape[-1]
     if softmax_scale is None:
         softmax_scale = 1.0 / math.sqrt(D)
+    lse_shape = (q.shape[0], q.shape[1], q.shape[2]) if layout == "bhnd" else (q.shape[0], q.shape[2], q.shape[1])   # (B,H,Nq)
+    if not lse.is_cuda or lse.device != q.device or lse.dtype != torch.float32 or tuple(lse.shape) != lse_shape:
+        raise RuntimeError(f"lse must be the forward's float32 {lse_shape} tensor on q's device "
+                           f"(got {lse.dtype} {tuple(lse.shape)} on {lse.device})")
+    if any(t.device != q.device for t in (k, v, out, dout)):
+        raise RuntimeError("q,k,v,out,dout must be on the same device")
     lse = lse.contiguous()
     gdt = torch.float32 if grad_f32 else q.dtype
     dq = torch.empty(q.shape, dtype=gdt, device=q.device)
