@@ -321,6 +321,36 @@ def abs_weighted(q, k, v, is_causal, softmax_scale):
     return exact64(q, k, v.abs(), is_causal, softmax_scale)
 
 
+def tiny_py_multihead(q, k, v, block_m=4):
+    """Restatement of the reference's pure-Python path, BASELINE config 1
+    (flash_attention_py/tiny_flash_attn.py:137-196 flash_attn_v2_multihead): a Python double loop over
+    block_m-row query blocks and block_m-key blocks of fp32 (B,H,N,D) CPU tensors, online softmax with a
+    running max / denominator per row, NO softmax scale and NO mask (:168-170), floor(N / block_m) blocks
+    (:154,164; trailing rows stay zero).  bench.py times this as the "Python CPU path" next to the GPU number;
+    tests/test_oracle.py pins it to the reference's own output (tests/golden/tiny_py_cfg1.npz)."""
+    q, k, v = q.float(), k.float(), v.float()
+    B, H, N, _ = q.shape
+    out = torch.zeros_like(v)
+    nblk = N // block_m
+    for jb in range(nblk):
+        rows = slice(jb * block_m, (jb + 1) * block_m)
+        qb = q[..., rows, :]
+        acc = out[..., rows, :]
+        den = torch.zeros((B, H, block_m, 1))
+        mx = torch.full((B, H, block_m, 1), -math.inf)
+        for ib in range(k.shape[-2] // block_m):
+            keys = slice(ib * block_m, (ib + 1) * block_m)
+            s = qb @ k[..., keys, :].transpose(2, 3)
+            mx_new = torch.maximum(mx, s.max(dim=-1, keepdim=True).values)
+            e = torch.exp(s - mx_new)
+            alpha = torch.exp(mx - mx_new)
+            den = den * alpha + e.sum(dim=-1, keepdim=True)
+            acc = acc * alpha + e @ v[..., keys, :]
+            mx = mx_new
+        out[..., rows, :] = acc / den
+    return out
+
+
 _ref_mod = None
 
 

@@ -144,6 +144,36 @@ def test_operator_error_behaviour_without_gpu():
         tfa.flash_attention_v2_cutlass(q, q, q)
 
 
+@pytest.mark.parametrize("module,names", [("attention_cutlass", ["flash_attention_v2_cutlass"]),
+                                          ("attention_cuda", ["self_attention_cuda", "flash_attention_v1_cuda", "flash_attention_v2_cuda"]),
+                                          ("_kernels", ["naive_attn", "flash_attn", "hello_world"])])
+def test_reference_named_extension_modules_import_and_reject_cpu_tensors(module, names):
+    """The three torch extension modules of the reference (flash_attention_cutlass/csrc/attention_api.cpp:6-10,
+    flash_attention_cuda/csrc/attention_api.cpp:6-14, flash_attention_c/csrc/ops.cu:4-8) are importable under their own
+    names from lib/, export the reference's function names, and refuse CPU tensors (there is no CPU path to fall into)."""
+    import importlib
+    import sys
+
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    sys.path.insert(0, libdir)
+    try:
+        sys.modules.pop(module, None)
+        mod = importlib.import_module(module)
+    finally:
+        sys.path.remove(libdir)
+    assert os.path.dirname(os.path.abspath(mod.__file__)) == os.path.abspath(libdir)
+    q = torch.zeros(1, 1, 64, 64, dtype=torch.float16)
+    for n in names:
+        fn = getattr(mod, n)
+        if n == "hello_world":
+            continue
+        args = (q, q, q) if module == "attention_cuda" else (q, q, q, True, 0.125)
+        with pytest.raises(RuntimeError, match="q must be a CUDA tensor"):
+            fn(*args)
+        with pytest.raises(TypeError):
+            fn(q, q)
+
+
 def test_variant_selection_is_introspectable_without_gpu():
     # big grids -> the 8-wave issue-interleaved kernel, small grids -> its 4-wave form (128-row blocks, 2 workgroups per CU)
     big = _lib.variant_for(4, 32, 32, 4096, 4096, 128, True)

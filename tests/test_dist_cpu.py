@@ -113,3 +113,49 @@ def test_kv_sharded_forward_gloo_world2(shape, causal):
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
+
+
+def _og_worker(rank, world, port, shape, causal, chunks, q_out):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from tiny_flash_attention_amd import dist as tdist
+
+    Bl, H, N, D = shape                                           # per-rank batch (weak scaling, as bench.py --gather)
+    q, k, v = O.make_inputs(Bl, H, N, D, torch.float32, seed=100 + rank)
+    sc = 1.0 / math.sqrt(D)
+
+    def fn(a, b, c, cz, s, o):
+        o.copy_(O.flash_attn(a.contiguous(), b.contiguous(), c.contiguous(), cz, s))
+
+    og = tdist.OverlappedGather(q, k, v, causal, sc, world, rank, chunks=chunks, fn=fn)
+    og.step()
+    og.step()                                                      # a second step re-uses the slabs
+    og.join()
+    ok = og.nchunks == min(chunks, Bl)
+    for r in range(world):                                         # every rank's slab, recomputed locally from its seed
+        qr, kr, vr = O.make_inputs(Bl, H, N, D, torch.float32, seed=100 + r)
+        ok = ok and bool(torch.equal(og.full[r * Bl:(r + 1) * Bl], O.flash_attn(qr, kr, vr, causal, sc)))
+    q_out.put((rank, ok, "og"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape,causal,chunks", [((4, 2, 64, 32), True, 4), ((3, 2, 48, 32), False, 2), ((1, 1, 32, 32), True, 4)])
+def test_overlapped_gather_gloo_world2(shape, causal, chunks):
+    """bench.py --gather's schedule (batch chunks: kernel c+1 beside gather c) assembles every rank's slab bit-exactly."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_og_worker, args=(r, 2, port, shape, causal, chunks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res

@@ -18,6 +18,8 @@ def test_golden_tiny_py_cfg1(oracle):
     for fn in (oracle.naive_attn, oracle.flash_attn, oracle.exact64):
         got = fn(q, k, v, False, 1.0)
         assert torch.allclose(got, want, rtol=0, atol=2e-6), fn.__name__
+    # the restated Python double loop (what bench.py times as the "Python CPU path") reproduces the reference's own output
+    assert torch.allclose(oracle.tiny_py_multihead(q, k, v, 4), want, rtol=0, atol=1e-6)
     # the reference's 2-D v1/v2 variants agree with head 0
     assert torch.allclose(torch.from_numpy(z["out_v1_head0"]), want[0, 0], atol=2e-6)
     assert torch.allclose(torch.from_numpy(z["out_v2_head0"]), want[0, 0], atol=2e-6)

@@ -87,3 +87,65 @@ def kv_sharded_forward(q, k_local, v_local, is_causal, softmax_scale, kv_offset,
     dist.all_gather_into_tensor(o_all.view(-1), o_l.view(-1), group=group)
     dist.all_gather_into_tensor(l_all.view(-1), l_l.view(-1), group=group)
     return merge_fn(o_all, l_all, out_dtype)
+
+
+class OverlappedGather:
+    """Forward over this rank's batch slab + the "trivial gather" of all ranks' outputs, with the gather hidden behind
+    the compute ("overlap the gather with compute by chunking over B").
+
+    The slab is cut into `chunks` contiguous batch chunks.  `step()` launches chunk c's kernel on the current stream and
+    queues chunk c's all-gather on a side stream behind an event, so that RCCL moves chunk c over xGMI while chunk c+1
+    computes; only the last chunk's gather is exposed.  (b,h) problems are independent
+    (flash_attention_cutlass/csrc/flash_attention.cu:382,409,698), so chunking changes no result bit.  `full` holds the
+    gathered output, rank r's batch b at row r*B + b; `join()` makes the current stream wait for the outstanding gathers.
+    `fn(q,k,v,is_causal,scale,out) -> None` defaults to the HIP operator writing into `out`; `device='cpu'` tensors
+    (the gloo tests) run the same schedule without streams."""
+
+    def __init__(self, q, k, v, is_causal, softmax_scale, world, rank, chunks=4, group=None, fn=None):
+        self.q, self.k, self.v = q, k, v
+        self.causal, self.scale = is_causal, softmax_scale
+        self.world, self.rank, self.group = world, rank, group
+        B = q.shape[0]
+        self.nchunks = max(1, min(int(chunks), B))
+        self.bounds = [shard_bounds(B, self.nchunks, c) for c in range(self.nchunks)]
+        self.out = torch.empty_like(q)
+        self.full = torch.empty((world * B,) + tuple(q.shape[1:]), dtype=q.dtype, device=q.device)
+        self.cuda = q.is_cuda
+        if fn is None:
+            fn = lambda a, b_, c, causal, sc, o: ops.flash_attn_fwd(a, b_, c, causal, sc, return_lse=False, out=o)
+        self.fn = fn
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=q.device)
+            self.computed = [torch.cuda.Event() for _ in self.bounds]
+            self.gathered = [None for _ in self.bounds]      # event of the chunk's last gather (its out slab is being read)
+
+    def _gather(self, lo, hi):
+        B = self.q.shape[0]
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            self.full[lo:hi].copy_(self.out[lo:hi])
+            return
+        dsts = [self.full[r * B + lo: r * B + hi] for r in range(self.world)]
+        dist.all_gather(dsts, self.out[lo:hi], group=self.group)
+
+    def step(self):
+        if not self.cuda:
+            for lo, hi in self.bounds:
+                self.fn(self.q[lo:hi], self.k[lo:hi], self.v[lo:hi], self.causal, self.scale, self.out[lo:hi])
+                self._gather(lo, hi)
+            return
+        main = torch.cuda.current_stream(self.q.device)
+        for c, (lo, hi) in enumerate(self.bounds):
+            if self.gathered[c] is not None:
+                main.wait_event(self.gathered[c])            # the previous step's gather still reads this out slab
+            self.fn(self.q[lo:hi], self.k[lo:hi], self.v[lo:hi], self.causal, self.scale, self.out[lo:hi])
+            self.computed[c].record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.computed[c])
+                self._gather(lo, hi)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                self.gathered[c] = ev
+
+    def join(self):
+        if self.cuda:
+            torch.cuda.current_stream(self.q.device).wait_stream(self.side)
