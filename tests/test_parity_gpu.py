@@ -101,10 +101,6 @@ def run_case(tfa, oracle, dev, dtype, B, H, N, D, causal, Hk=None, Nk=None, seed
     check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype)
 
 
-# measured on MI355X (tests/tools/ref_rounding_stats.py, profiles/r02_ref_rounding_stats.txt): fraction of fp32-output
-# elements outside rtol 1e-3 (+1e-4*A) when the il kernels are compared with the reference's exact-max rounding points
-REF_ROUNDING_T2_FRACTION = 5e-2
-
 SHAPES = [
     # dtype, B, H, N, D, causal
     (torch.bfloat16, 1, 2, 256, 128, False),
@@ -342,32 +338,31 @@ def test_long_context_cfg4_one_head_vs_oracle(tfa, oracle, dev, causal):
 
 
 @pytest.mark.parametrize("dtype,N,D,causal", [(torch.bfloat16, 2048, 128, True), (torch.bfloat16, 1024, 128, False),
-                                              (torch.float16, 1024, 64, True)])
+                                              (torch.float16, 1024, 64, True), (torch.float16, 2048, 128, False)])
 def test_against_the_references_rounding_points(tfa, oracle, dev, dtype, N, D, causal):
     """The product kernels round P against a lazily re-based row reference; the reference's tile loop
     (flash_attention_py/main_torch_only.py:240-260, restated as oracle.tiled_emulation, block_n = 64) rounds it against
-    the exact running max.  The two are different roundings of the same P, so this states the il kernels' error against the
-    REFERENCE's rounding points without leaning on the kernel-derived emulation: fp32 output within rtol 1e-3 (+1e-4*A) on
-    all but a small fraction of elements, every element within twice the rigorous P-rounding bound, and the 16-bit output
-    within one ulp of the reference-rounding result almost everywhere."""
+    the exact running max.  Same P, different 16-bit rounding grids — so this states the il kernels' error against the
+    REFERENCE's rounding points without leaning on the kernel-derived emulation.  Measured on MI355X
+    (tests/tools/ref_rounding_stats.py -> profiles/r02_ref_rounding_stats.txt): max |d| = 0.08..0.21 of eps*A
+    (eps = one 16-bit ulp of P: 2^-8 bf16, 2^-11 fp16; A = sum_j P|v|), i.e. fp16 meets rtol 1e-3 + 1e-4*A on every
+    element, bf16 on 87-92 % of them with the rest inside 0.21 * 2^-8 * A.  Asserted: every element within
+    rtol 1e-3 + max(1e-4, eps/2) * A — a quarter of what two different roundings of P may differ by (2 * eps * A)."""
     from tiny_flash_attention_amd import ops
 
     q, k, v = oracle.make_inputs(2, 4, N, D, dtype, seed=31)
     sc = 1.0 / math.sqrt(D)
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
-    out16, _ = ops.flash_attn_fwd(qd, kd, vd, causal, sc)
     out32, _ = ops.flash_attn_fwd(qd, kd, vd, causal, sc, out_f32=True)
     torch.cuda.synchronize()
     emu = oracle.tiled_emulation(q, k, v, causal, sc, 64)
     A = oracle.abs_weighted(q, k, v, causal, sc)
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     d = (out32.cpu() - emu).abs()
-    assert bool((d <= 2 * eps * A + 1e-6).all()), f"beyond twice the P-rounding bound: {(d - 2 * eps * A).max().item():.3e}"
-    frac = (d > 1e-3 * emu.abs() + 1e-4 * A).float().mean().item()
-    assert frac <= REF_ROUNDING_T2_FRACTION, f"rtol=1e-3 vs the reference's rounding points violated by {frac:.3e} of elements"
-    u = ulp16(emu, dtype)
-    d16 = (out16.float().cpu() - emu.to(dtype).float()).abs()
-    assert bool((d16 <= 2 * u).all()) and (d16 > u * (1 + 1e-6)).float().mean().item() <= 1e-3
+    bound = 1e-3 * emu.abs() + max(1e-4, 0.5 * eps) * A + 1e-6
+    assert bool((d <= bound).all()), f"vs the reference's rounding points: worst excess {(d - bound).max().item():.3e}"
+    if dtype == torch.float16:      # fp16's ulp is small enough for the plain rtol = 1e-3 statement (T2) to hold element-wise
+        assert bool((d <= 1e-3 * emu.abs() + 1e-4 * A + 1e-6).all())
 
 
 def test_headline_properties(tfa, dev):
