@@ -117,7 +117,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29, 30, 31, 32])
+@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29, 30, 31, 32, 33])
 @pytest.mark.parametrize("dtype,B,H,N,D,causal", SHAPES)
 def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
     from tiny_flash_attention_amd import _lib
@@ -130,7 +130,7 @@ def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causa
         _lib.set_variant(-1)
 
 
-@pytest.mark.parametrize("variant", [-1, 17, 30, 31])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
+@pytest.mark.parametrize("variant", [-1, 17, 30, 31, 33])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
 @pytest.mark.parametrize("Nq,Nk,causal", [(128, 384, True), (384, 128, True), (100, 333, False), (1, 1000, True), (257, 64, False),
                                           (700, 1500, True), (1111, 1111, False)])
 def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
@@ -231,7 +231,7 @@ def test_inputs_not_modified_and_deterministic(tfa, oracle, dev):
 # ---------------------------------------------------------------------------------------------
 # data-dependent branch: the exact "max unchanged -> skip the O rescale" path and late max jumps
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [1, 2, 5, 10, 11, 14, 15, 17, 18, 19, 20, 22, 26, 27, 28, 30, 31, 32])
+@pytest.mark.parametrize("variant", [1, 2, 5, 10, 11, 14, 15, 17, 18, 19, 20, 22, 26, 27, 28, 30, 31, 32, 33])
 def test_late_max_jump_spike(tfa, oracle, dev, variant):
     from tiny_flash_attention_amd import _lib, ops
 
@@ -423,7 +423,7 @@ def test_long_context_cfg4_properties(tfa, dev):
     assert (out_k.float() - out[:, :2].float()).abs().max().item() <= 1e-2 * out.float().abs().max().item() + 2 ** -9
 
 
-@pytest.mark.parametrize("variant", [-1, 27, 30])
+@pytest.mark.parametrize("variant", [-1, 27, 30, 33])
 def test_strided_bnhd_matches_bhnd(tfa, oracle, dev, variant):
     from tiny_flash_attention_amd import _lib, ops
 

@@ -64,7 +64,7 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   if (p->B <= 0 || p->H <= 0 || p->Hk <= 0 || p->Nq <= 0 || p->Nk <= 0) return TFA_ERR_SHAPE;
   if (p->H % p->Hk != 0) return TFA_ERR_SHAPE;
   if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
-  const bool ablate = (variant >= 100 && variant < 100 + 512) || (variant >= 700 && variant < 716) || (variant >= 1000 && variant < 2256);   // timing-only ablations (debug)
+  const bool ablate = (variant >= 100 && variant < 100 + 512) || (variant >= 700 && variant < 716) || (variant >= 1000 && variant < 2256) || (variant >= 3000 && variant < 3256);   // timing-only ablations (debug)
   if (!ablate && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
   const int esz = 2, osz = (p->out_dtype == TFA_F32) ? 4 : 2;
   const int64_t* st[4] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride};
@@ -277,7 +277,7 @@ int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, f
 }
 
 int tfa_set_variant(int variant) {
-  if (variant < -1 || (variant >= tfa::kNumVariants && (variant < 100 || variant >= 2256 || (variant >= 716 && variant < 1000) || (variant >= 612 && variant < 700)))) return TFA_ERR_VARIANT;
+  if (variant < -1 || (variant >= tfa::kNumVariants && (variant < 100 || variant >= 2256 || (variant >= 716 && variant < 1000) || (variant >= 612 && variant < 700))) && !(variant >= 3000 && variant < 3256)) return TFA_ERR_VARIANT;
   if (variant >= 0 && variant < tfa::kNumVariants && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
   g_variant = variant;
   return TFA_OK;

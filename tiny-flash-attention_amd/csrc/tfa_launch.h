@@ -8,6 +8,7 @@
 #include "tfa_fwd_kernel.h"
 #include "tfa_fwd_kernel_dma.h"
 #include "tfa_fwd_kernel_il.h"
+#include "tfa_fwd_kernel_x4.h"
 #if defined(TFA_EXPERIMENTAL)
 #include "tfa_fwd_kernel_pp.h"
 #include "tfa_fwd_kernel_swp.h"
@@ -58,10 +59,12 @@ static const Variant kVariants[] = {
     {"il8-pair-dmaspread-epi (O leaves through a separate LDS region as whole rows, 16-byte stores)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
     {"il8-pair-dmaspread-epi-pref (+ the next pass's first tiles and Q requested before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF, 1},
     {"il4-pair-epi (4 waves x2 workgroups per CU; O leaves through the idle tile buffers as whole rows)", 4, VF_DMA | VF_IL | VF_PAIR | VF_IL_EPI | VF_IL_EPI_INPLACE, 1},
+    {"il-x4-pair-epi (issue-interleaved, 4 waves x 64 rows: one wave per SIMD, O and Q in AGPRs, K ring of three LDS buffers)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR | VF_X4_EPI, 2},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
 constexpr int kSmallGridVariant = 32;     // il4-pair-epi (128-row query blocks, two workgroups per CU)
+constexpr int kX4Variant = 33;            // il-x4-pair-epi
 constexpr int kSplitVariant = 17;         // dma4-pair-2buf: the kernel whose grid can carry key chunks (tfa_fwd_splitkv)
 
 struct LaunchGeom {
@@ -77,7 +80,7 @@ static inline bool variant_built(int variant) {
 #if defined(TFA_EXPERIMENTAL)
   return true;
 #else
-  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant;
+  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant || variant == kX4Variant;
 #endif
 }
 
@@ -94,6 +97,10 @@ static inline hipError_t launch_common(Kern kern, std::atomic<unsigned long long
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, a);
   return hipGetLastError();
 }
+
+// defined in tfa_x4_inst_<dtype>_<D>.hip; ablate != 0 selects a timing-only ablation (EXPERIMENTAL builds)
+template <typename T, int D>
+hipError_t launch_x4_unit(const KArgs& a, bool causal, bool f32out, int ablate, hipStream_t stream, LaunchGeom* geom, bool dry);
 
 static inline int block_m_of(int variant) { return kVariants[variant].nw * 32 * kVariants[variant].rb; }
 static inline bool uses_dma(int variant) { return (kVariants[variant].vf & VF_DMA) != 0; }

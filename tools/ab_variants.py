@@ -1,0 +1,44 @@
+"""Interleaved A/B timing of kernel variants of the loaded library on the BASELINE shapes (same process, same inputs).
+usage: python tools/ab_variants.py --variants 30,33 [--cfgs cfg3,cfg3nc,cfg4] [--rounds 5] [--iters 30]"""
+import argparse, ctypes as C, math, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tiny_flash_attention_amd import _lib, ops
+CFG = {"cfg2": (4, 8, 1024, 64, torch.float16, False), "cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096, 128, torch.bfloat16, False),
+       "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg4c": (1, 16, 16384, 128, torch.bfloat16, True), "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),
+       "d64": (4, 32, 4096, 64, torch.float16, False), "d64c": (4, 32, 4096, 64, torch.float16, True), "n2k": (8, 32, 2048, 128, torch.bfloat16, True),
+       "n1k": (16, 32, 1024, 128, torch.bfloat16, True)}
+ap = argparse.ArgumentParser()
+ap.add_argument("--variants", default="30,33")
+ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4")
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--warm", type=float, default=1.0, help="seconds of pre-conditioning launches before the rounds")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+L = _lib.lib()
+vs = [int(x) for x in a.variants.split(",")]
+import time
+for cfg in a.cfgs.split(","):
+    B, H, N, D, dt, causal = CFG[cfg]
+    mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(dt)
+    q, k, v = mk(), mk(), mk()
+    out = torch.empty_like(q); lse = torch.empty((B, H, N), dtype=torch.float32, device=dev)
+    p = ops.make_params(q, k, v, out, lse, causal, 1 / math.sqrt(D))
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fl, by = C.c_double(), C.c_double()
+    L.tfa_fwd_work(C.byref(p), C.byref(fl), C.byref(by))
+    ms = C.c_float()
+    t0 = time.time()
+    _lib.set_variant(vs[0])
+    while time.time() - t0 < a.warm:
+        _lib.check(L.tfa_fwd_time(C.byref(p), 0, 50, s, C.byref(ms)))
+    res = {v: [] for v in vs}
+    for r in range(a.rounds):
+        for vv in vs:
+            _lib.set_variant(vv)
+            _lib.check(L.tfa_fwd_time(C.byref(p), 3, a.iters, s, C.byref(ms)))
+            res[vv].append(fl.value / (ms.value * 1e-3) / 1e12)
+    _lib.set_variant(-1)
+    print(cfg, " ".join(f"v{vv}: med {sorted(res[vv])[len(res[vv]) // 2]:7.1f} max {max(res[vv]):7.1f} TF" for vv in vs), flush=True)

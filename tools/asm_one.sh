@@ -1,0 +1,11 @@
+#!/bin/bash
+# Compile ONE instantiation of the x4 kernel (bf16, D=128, 16-bit out; ONE_CAUSAL / ONE_AB / extra -D via $EXTRA) and report
+# registers, spills and the hot-loop statistics.  Output in /tmp/x4/.
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd /tmp/x4
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$ROOT/tiny-flash-attention_amd/csrc -Wall -Wno-unused-function -Wno-inline-asm -fno-gpu-rdc -mllvm -amdgpu-early-inline-all=true --cuda-device-only -save-temps -Rpass-analysis=kernel-resource-usage $EXTRA -c one.hip -o one.o 2> res.txt || { grep -E "error" -A3 res.txt | head -30; exit 1; }
+grep -E "VGPRs:|AGPRs|Spill|ScratchSize" res.txt | sed 's/remark: [^ ]* *//; s/\[-Rpass.*//' | tr '\n' ' '; echo
+S=$(ls one-hip-amdgcn*.s | head -1)
+awk '/^_ZN3tfa13fwd_kernel_x4/,/s_endpgm/' $S > one.s
+echo "one.s: $(wc -l < one.s) lines, scratch ops $(grep -c scratch_ one.s), v_accvgpr $(grep -c v_accvgpr one.s), mfma $(grep -c v_mfma one.s)"
+python3 $ROOT/tools/x4_loop_stats.py /tmp/x4/one.s --min 40 | grep -v "VALU ops"
