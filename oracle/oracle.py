@@ -362,7 +362,9 @@ def ref_kernels():
         cands = glob.glob(os.path.join(_HERE, "_ref", "_kernels*.so"))
         if not cands:
             return None
-        spec = importlib.util.spec_from_file_location("_kernels", cands[0])
+        # a qualified name: the GPU product ships its own module called `_kernels` (the reference's name), and CPython hands
+        # back an already-loaded extension module of the same name instead of loading this file
+        spec = importlib.util.spec_from_file_location("tfa_oracle_ref._kernels", cands[0])
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         _ref_mod = mod

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"include/tfa.h declares {n} but libtfa_hip.so does not export it"
     assert sorted(_lib.SYMBOLS) == names
-    assert L.tfa_version() == 102
+    assert L.tfa_version() == 103
 
 
 def _params(B=2, H=4, Hk=4, Nq=128, Nk=128, D=128, dtype=_lib.TFA_BF16, out_dtype=None, scale=0.1, base=0x10000):
@@ -97,7 +97,9 @@ def test_rejects_bad_descriptors():
     p = _params(); p.q = None; cases.append((p, -1))
     cases.append((_params(dtype=2), -2))
     cases.append((_params(out_dtype=0), -2))           # bf16 in, f16 out
-    cases.append((_params(D=96), -3))
+    cases.append((_params(D=100), -3))                 # not a multiple of 8
+    cases.append((_params(D=136), -3))                 # beyond the 128-wide kernel (the reference's 160..256 buckets)
+    assert plan(_params(D=96))[0] == 0 and plan(_params(D=32, dtype=_lib.TFA_F16))[0] == 0 and plan(_params(D=8))[0] == 0
     cases.append((_params(Nq=0), -4))
     cases.append((_params(H=6, Hk=4), -4))
     p = _params(); p.k_stride[2] = 100; cases.append((p, -5))   # row stride not 16-byte aligned
@@ -161,6 +163,7 @@ def test_reference_named_extension_modules_import_and_reject_cpu_tensors(module,
         mod = importlib.import_module(module)
     finally:
         sys.path.remove(libdir)
+        sys.modules.pop(module, None)
     assert os.path.dirname(os.path.abspath(mod.__file__)) == os.path.abspath(libdir)
     q = torch.zeros(1, 1, 64, 64, dtype=torch.float16)
     for n in names:
@@ -186,7 +189,7 @@ def test_variant_selection_is_introspectable_without_gpu():
     finally:
         _lib.set_variant(-1)
     with pytest.raises(_lib.TfaError):
-        _lib.variant_for(1, 1, 1, 16, 16, 96, False)                         # unsupported head dim
+        _lib.variant_for(1, 1, 1, 16, 16, 100, False)                        # unsupported head dim
 
 
 def test_il_kernels_leave_the_pinned_accumulator_registers_alone():

@@ -117,7 +117,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29, 30, 31, 32, 33])
+@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29, 30, 31, 32, 33, 34])
 @pytest.mark.parametrize("dtype,B,H,N,D,causal", SHAPES)
 def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
     from tiny_flash_attention_amd import _lib
@@ -130,7 +130,7 @@ def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causa
         _lib.set_variant(-1)
 
 
-@pytest.mark.parametrize("variant", [-1, 17, 30, 31, 33])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
+@pytest.mark.parametrize("variant", [-1, 17, 30, 31, 33, 34])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
 @pytest.mark.parametrize("Nq,Nk,causal", [(128, 384, True), (384, 128, True), (100, 333, False), (1, 1000, True), (257, 64, False),
                                           (700, 1500, True), (1111, 1111, False)])
 def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
@@ -145,6 +145,47 @@ def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
         run_case(tfa, oracle, dev, torch.float16, 2, 6, Nq, 64, causal, Hk=1, Nk=Nk, seed=8)
     finally:
         _lib.set_variant(-1)
+
+
+# head dims: every multiple of 8 up to 128 runs on the 64- or 128-wide kernel with the columns beyond D read as zeros (the
+# LDS-DMA lanes and Q loads of those 16-byte chunks are pointed out of the buffer's range) and never stored.  The reference
+# dispatches D in {32, 64, 96, 128, ...} (flash_attention_cutlass/csrc/static_switch.h:39-66).
+@pytest.mark.parametrize("variant", [-1, 17, 30, 33])
+@pytest.mark.parametrize("dtype,B,H,N,D,causal", [
+    (torch.bfloat16, 2, 3, 384, 96, True),
+    (torch.float16, 1, 4, 512, 32, False),
+    (torch.bfloat16, 1, 2, 200, 96, False),      # ragged N as well
+    (torch.float16, 2, 2, 320, 32, True),
+    (torch.bfloat16, 1, 2, 256, 72, True),       # not one of the reference's buckets: any multiple of 8 works
+    (torch.float16, 1, 1, 128, 8, False),
+    (torch.bfloat16, 1, 2, 192, 120, True),
+])
+def test_head_dims_below_the_kernel_width(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
+    from tiny_flash_attention_amd import _lib
+
+    _need_variant(variant)
+    _lib.set_variant(variant)
+    try:
+        run_case(tfa, oracle, dev, dtype, B, H, N, D, causal, seed=40 + D)
+    finally:
+        _lib.set_variant(-1)
+
+
+def test_head_dim_96_gqa_strided_and_reference_binding(tfa, oracle, dev):
+    # D=96 through the (B,N,H,D) strided entry with fewer K/V heads, and through the reference-named entry point
+    from tiny_flash_attention_amd import ops
+
+    q, k, v = oracle.make_inputs(2, 8, 300, 96, torch.bfloat16, seed=77, Hk=2)
+    sc = 1.0 / math.sqrt(96)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    o_bhnd, l_bhnd = ops.flash_attn_fwd(qd, kd, vd, True, sc)
+    qt, kt, vt = (t.transpose(1, 2).contiguous() for t in (qd, kd, vd))
+    o_bnhd, l_bnhd = ops.flash_attn_fwd(qt, kt, vt, True, sc, layout="bnhd")
+    check(oracle, o_bhnd, None, l_bhnd, q, k, v, True, sc, torch.bfloat16)
+    assert torch.equal(o_bnhd.transpose(1, 2), o_bhnd) and torch.equal(l_bnhd, l_bhnd)
+    q2, k2, v2 = oracle.make_inputs(1, 4, 256, 32, torch.float16, seed=78)
+    out, lse = tfa.flash_attention_v2_cutlass(q2.to(dev), k2.to(dev), v2.to(dev), True, 1.0 / math.sqrt(32))
+    check(oracle, out, None, lse, q2, k2, v2, True, 1.0 / math.sqrt(32), torch.float16)
 
 
 def test_baseline_cfg2_full(tfa, oracle, dev):
@@ -231,7 +272,7 @@ def test_inputs_not_modified_and_deterministic(tfa, oracle, dev):
 # ---------------------------------------------------------------------------------------------
 # data-dependent branch: the exact "max unchanged -> skip the O rescale" path and late max jumps
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [1, 2, 5, 10, 11, 14, 15, 17, 18, 19, 20, 22, 26, 27, 28, 30, 31, 32, 33])
+@pytest.mark.parametrize("variant", [1, 2, 5, 10, 11, 14, 15, 17, 18, 19, 20, 22, 26, 27, 28, 30, 31, 32, 33, 34])
 def test_late_max_jump_spike(tfa, oracle, dev, variant):
     from tiny_flash_attention_amd import _lib, ops
 

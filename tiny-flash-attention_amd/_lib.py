@@ -25,6 +25,7 @@ SYMBOLS = (
     "tfa_variant_available",
     "tfa_fwd_work",
     "tfa_debug_set_trace",
+    "tfa_debug_set_flags",
     "tfa_merge",
     "tfa_fwd_splitkv",
     "tfa_fwd_splitkv_workspace",
@@ -143,6 +144,8 @@ def lib():
     L.tfa_variant_name.argtypes = [C.c_int]
     L.tfa_variant_available.restype = C.c_int
     L.tfa_variant_available.argtypes = [C.c_int]
+    L.tfa_debug_set_flags.restype = C.c_int
+    L.tfa_debug_set_flags.argtypes = [C.c_int]
     L.tfa_debug_set_trace.restype = C.c_int
     L.tfa_debug_set_trace.argtypes = [C.c_void_p]
     L.tfa_fwd_splitkv.restype = C.c_int

@@ -55,7 +55,9 @@ void* current_stream(const torch::Tensor& q) {
 }  // namespace
 
 #if TFA_BINDING == 1
-std::vector<torch::Tensor> flash_attention_v2_cutlass(torch::Tensor q, torch::Tensor k, torch::Tensor v,
+// (all binding functions have internal linkage: the reference's own modules export the same C++ names, and two modules
+// loaded into one process must not interpose each other's symbols — the oracle loads the reference-built _kernels)
+static std::vector<torch::Tensor> flash_attention_v2_cutlass(torch::Tensor q, torch::Tensor k, torch::Tensor v,
                                                       bool is_causal = false, float softmax_scale = 1) {
   CHECK_INPUT(q);
   CHECK_INPUT(k);
@@ -98,9 +100,9 @@ static torch::Tensor attention_3arg(const torch::Tensor& q, const torch::Tensor&
   TORCH_CHECK(st == 0, tfa_strerror(st));
   return out;
 }
-torch::Tensor flash_attention_v2_cuda(torch::Tensor q, torch::Tensor k, torch::Tensor v) { return attention_3arg(q, k, v, "flash_attention_v2_cuda"); }
-torch::Tensor flash_attention_v1_cuda(torch::Tensor q, torch::Tensor k, torch::Tensor v) { return attention_3arg(q, k, v, "flash_attention_v1_cuda"); }
-torch::Tensor self_attention_cuda(torch::Tensor q, torch::Tensor k, torch::Tensor v) { return attention_3arg(q, k, v, "self_attention_cuda"); }
+static torch::Tensor flash_attention_v2_cuda(torch::Tensor q, torch::Tensor k, torch::Tensor v) { return attention_3arg(q, k, v, "flash_attention_v2_cuda"); }
+static torch::Tensor flash_attention_v1_cuda(torch::Tensor q, torch::Tensor k, torch::Tensor v) { return attention_3arg(q, k, v, "flash_attention_v1_cuda"); }
+static torch::Tensor self_attention_cuda(torch::Tensor q, torch::Tensor k, torch::Tensor v) { return attention_3arg(q, k, v, "self_attention_cuda"); }
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("self_attention_cuda", &self_attention_cuda, "Self attention forward (MI355X HIP flash kernel; same function as the naive reference kernel)");
@@ -135,13 +137,13 @@ static torch::Tensor attn_strided(const torch::Tensor& q, const torch::Tensor& k
   TORCH_CHECK(rc == 0, tfa_strerror(rc));
   return out;
 }
-torch::Tensor flash_attn(torch::Tensor q, torch::Tensor k, torch::Tensor v, bool is_causal = false, float softmax_scale = 1) {
+static torch::Tensor flash_attn(torch::Tensor q, torch::Tensor k, torch::Tensor v, bool is_causal = false, float softmax_scale = 1) {
   return attn_strided(q, k, v, is_causal, softmax_scale, "flash_attn");
 }
-torch::Tensor naive_attn(torch::Tensor q, torch::Tensor k, torch::Tensor v, bool is_causal = false, float softmax_scale = 1) {
+static torch::Tensor naive_attn(torch::Tensor q, torch::Tensor k, torch::Tensor v, bool is_causal = false, float softmax_scale = 1) {
   return attn_strided(q, k, v, is_causal, softmax_scale, "naive_attn");   // same function by a different route in the reference (attn.cpp:35-98)
 }
-void hello_world() { std::cout << "Hello, World!" << std::endl; }
+static void hello_world() { std::cout << "Hello, World!" << std::endl; }
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("hello_world", &hello_world, "placeholder kept for name parity with the reference module");

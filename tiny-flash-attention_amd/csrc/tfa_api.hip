@@ -24,7 +24,8 @@ namespace {
 // Debug knobs (tfa_set_variant, tfa_debug_set_trace) are PER THREAD: a thread that forces a variant or a trace buffer
 // for an A/B measurement does not change what any other thread's calls run.  Nothing else in the library is mutable.
 thread_local int g_variant = -1;   // -1 = automatic
-thread_local unsigned long long* g_trace = nullptr;   // per-workgroup cycle stamps (tfa_debug_set_trace)
+thread_local unsigned long long* g_trace = nullptr;
+thread_local int g_dbg_flags = 0;                    // kernel bring-up flags (tfa_debug_set_flags): KArgs::dbg   // per-workgroup cycle stamps (tfa_debug_set_trace)
 
 int num_cus() { return tfa::num_cus_current_device(); }
 
@@ -60,12 +61,13 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   if (!p->q || !p->k || !p->v || !p->out) return TFA_ERR_NULL;
   if (p->dtype != TFA_F16 && p->dtype != TFA_BF16) return TFA_ERR_DTYPE;
   if (p->out_dtype != p->dtype && p->out_dtype != TFA_F32) return TFA_ERR_DTYPE;
-  if (p->D != 64 && p->D != 128) return TFA_ERR_HEAD_DIM;
+  if (p->D < 8 || p->D > 128 || (p->D % 8) != 0) return TFA_ERR_HEAD_DIM;   // > 128 (the reference's 160..256 buckets) needs its own kernel
   if (p->B <= 0 || p->H <= 0 || p->Hk <= 0 || p->Nq <= 0 || p->Nk <= 0) return TFA_ERR_SHAPE;
   if (p->H % p->Hk != 0) return TFA_ERR_SHAPE;
   if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
   const bool ablate = (variant >= 100 && variant < 100 + 512) || (variant >= 700 && variant < 716) || (variant >= 1000 && variant < 2256) || (variant >= 3000 && variant < 3256);   // timing-only ablations (debug)
   if (!ablate && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
+  if (p->D != 64 && p->D != 128 && (ablate || !tfa::supports_padded_d(variant))) return TFA_ERR_HEAD_DIM;   // (A/B arms: 64 / 128 only)
   const int esz = 2, osz = (p->out_dtype == TFA_F32) ? 4 : 2;
   const int64_t* st[4] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride};
   for (int t = 0; t < 4; ++t) {
@@ -106,6 +108,8 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   const int64_t nbh = (int64_t)p->B * p->H;
   if (nbh * a->nwork >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
   a->nbh = (int)nbh;
+  a->dbg = g_dbg_flags;
+  a->dv = p->D;
   return TFA_OK;
 }
 
@@ -118,12 +122,13 @@ int run(const tfa_fwd_params* p, void* stream, tfa::LaunchGeom* geom, bool dry) 
   const bool f32out = p->out_dtype == TFA_F32;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipError_t e;
+  const bool wide = p->D > 64;   // kernel width: 64 serves D <= 64, 128 serves 64 < D <= 128 (KArgs::dv = the valid part)
   if (p->dtype == TFA_BF16) {
-    e = (p->D == 128) ? tfa::launch_fwd<__bf16, 128>(a, causal, f32out, variant, s, geom, dry)
-                      : tfa::launch_fwd<__bf16, 64>(a, causal, f32out, variant, s, geom, dry);
+    e = wide ? tfa::launch_fwd<__bf16, 128>(a, causal, f32out, variant, s, geom, dry)
+             : tfa::launch_fwd<__bf16, 64>(a, causal, f32out, variant, s, geom, dry);
   } else {
-    e = (p->D == 128) ? tfa::launch_fwd<_Float16, 128>(a, causal, f32out, variant, s, geom, dry)
-                      : tfa::launch_fwd<_Float16, 64>(a, causal, f32out, variant, s, geom, dry);
+    e = wide ? tfa::launch_fwd<_Float16, 128>(a, causal, f32out, variant, s, geom, dry)
+             : tfa::launch_fwd<_Float16, 64>(a, causal, f32out, variant, s, geom, dry);
   }
   return (int)e;
 }
@@ -150,7 +155,7 @@ const char* tfa_strerror(int status) {
     case TFA_OK: return "success";
     case TFA_ERR_NULL: return "tfa: a required pointer is NULL";
     case TFA_ERR_DTYPE: return "tfa: unsupported dtype (q/k/v must be fp16 or bf16; out must match or be fp32)";
-    case TFA_ERR_HEAD_DIM: return "tfa: unsupported head dim (supported: 64, 128)";
+    case TFA_ERR_HEAD_DIM: return "tfa: unsupported head dim (forward: multiples of 8 up to 128; split-KV, merge and backward: 64, 128)";
     case TFA_ERR_SHAPE: return "tfa: bad shape (sizes must be positive and H % Hk == 0)";
     case TFA_ERR_STRIDE: return "tfa: bad stride (must be >=0, rows 16-byte aligned and non-overlapping, slice < 2 GiB)";
     case TFA_ERR_ALIGN: return "tfa: base pointers must be 16-byte aligned";
@@ -211,6 +216,7 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   int ns = 0, ch = 0;
   int st = splitkv_geometry(p, splits, &ns, &ch);
   if (st != TFA_OK) return st;
+  if (p->D != 64 && p->D != 128) return TFA_ERR_HEAD_DIM;   // the merge kernel's row layout
   if (!workspace || ((uintptr_t)workspace & 15)) return workspace ? TFA_ERR_ALIGN : TFA_ERR_NULL;
   // the merge writes contiguous rows: out must be a contiguous (B,H,Nq,D) tensor
   if (p->o_stride[2] != p->D || p->o_stride[1] != (int64_t)p->Nq * p->D || p->o_stride[0] != (int64_t)p->H * p->Nq * p->D) return TFA_ERR_STRIDE;
@@ -283,6 +289,7 @@ int tfa_set_variant(int variant) {
   return TFA_OK;
 }
 int tfa_get_variant(void) { return g_variant; }
+int tfa_debug_set_flags(int flags) { g_dbg_flags = flags; return TFA_OK; }
 int tfa_debug_set_trace(void* dev_buf) { g_trace = reinterpret_cast<unsigned long long*>(dev_buf); return TFA_OK; }
 int tfa_num_variants(void) { return tfa::kNumVariants; }
 int tfa_variant_available(int variant) { return tfa::variant_built(variant) ? 1 : 0; }

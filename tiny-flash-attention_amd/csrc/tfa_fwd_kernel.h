@@ -60,6 +60,10 @@ struct KArgs {
   float scale_log2; // softmax_scale * log2(e)
   int grid;         // workgroups launched (persistent kernels walk work items with this stride)
   unsigned long long* trace;  // debug: 8 x u64 per workgroup (cycle stamps), or nullptr
+  int dv;           // valid head dim (<= the kernel's compile-time D, a multiple of 8): the 16-byte chunks of a row beyond dv are
+                    // read as zeros (their LDS-DMA lanes / Q loads are pointed outside the buffer) and never stored
+  int dbg;          // bring-up flags (tfa_debug_set_flags; 0 in normal use).  128: the trace stamps describe the workgroup's
+                    // SECOND pass (t[0] = its start) instead of the first; low bits: tfa_fwd_kernel_x4.h
 };
 
 template <typename T> struct Elem;
@@ -135,6 +139,10 @@ template <int D> static __device__ __forceinline__ int v_lds_off(int key, int ch
   const int hi = (kk >> 2) & 1, half = kk >> 3, r4 = kk & 3;
   return (((s * 2 + hi) * (D / 32) + (chunk >> 2)) << 9) + ((half * 4 + r4) << 6) + ((chunk & 3) << 4);
 }
+
+// byte offset that every buffer descriptor of these kernels rejects (slices are < 2 GiB): reads return 0, stores are dropped.
+// Used with UNSIGNED arithmetic: OOB + any tile offset (< 2^31) stays >= 2^31 without wrapping.
+constexpr unsigned TFA_OOB = 0x80000000u;
 
 // Variant flags
 constexpr int VF_TRREAD = 1;     // V fragments by ds_read_b64_tr_b16 (else 16-bit gathers)

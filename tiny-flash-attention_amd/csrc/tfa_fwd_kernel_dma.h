@@ -104,14 +104,15 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
     {  // K: row-major, chunk position c' holds source chunk c' ^ swz(row)
       const int row = pc * (1024 / (D * 2)) + lane / CPR;
       const int cpos = lane % CPR;
-      k_src[i] = row * (int)p.ks_n * 2 + ((cpos ^ k_swz<D>(row)) << 4);
+      const int kch = cpos ^ k_swz<D>(row);            // source chunk of this lane; chunks beyond the valid head dim read as zeros
+      k_src[i] = kch * 8 < p.dv ? row * (int)p.ks_n * 2 + (kch << 4) : (int)TFA_OOB;
     }
     {  // V: invert v_lds_off(): LDS offset -> (key, 16-byte chunk)
       const int o = pc * 1024 + lane * 16;
       const int sub = o >> 9, R = (o >> 6) & 7, pcs = (o >> 4) & 3;
       const int dt = sub % DT, sh = sub / DT;
       const int key = 16 * (sh >> 1) + 4 * (sh & 1) + 8 * (R >> 2) + (R & 3);
-      v_src[i] = key * (int)p.vs_n * 2 + ((dt * 4 + pcs) << 4);
+      v_src[i] = (dt * 4 + pcs) * 8 < p.dv ? key * (int)p.vs_n * 2 + ((dt * 4 + pcs) << 4) : (int)TFA_OOB;
     }
   }
   const int k_tile_stride = BN * (int)p.ks_n * 2;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
     const int qoff = row * (int)p.qs_n * 2 + hi * 16;
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
-      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(k.q_rs, qoff + s * 32, 0, 0);
+      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(k.q_rs, (2 * s + hi) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB, 0, 0);
       qf[s] = __builtin_bit_cast(X8, t);
     }
   };
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4 v4 = {oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, ooff + (d * 32 + g * 8) * 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, d * 32 + g * 8 + hi * 4 < p.dv ? ooff + (d * 32 + g * 8) * 4 : (int)TFA_OOB, 0, 0);
         }
     } else if (LDS_EPI) {
       // Each lane holds 4-element pieces of ONE row scattered over 16 registers groups: stored directly that is
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
         const int r = i * RPI + lane / CH, cpos = lane % CH;
         const int c = cpos ^ ((CH == 16) ? (r & 15) : (r & 7));
         u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
-        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, (wave_row0 + r) * (int)p.os_n * 2 + (c << 4), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, 0);
       }
       if (have_next) {
         // the next block's DMA will overwrite these slices: every wave must have read its rows back
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           t4 v4 = {(T)(oacc[d][4 * g + 0] * inv), (T)(oacc[d][4 * g + 1] * inv), (T)(oacc[d][4 * g + 2] * inv), (T)(oacc[d][4 * g + 3] * inv)};
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, ooff + (d * 32 + g * 8) * 2, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, d * 32 + g * 8 + hi * 4 < p.dv ? ooff + (d * 32 + g * 8) * 2 : (int)TFA_OOB, 0, 0);
         }
     }
     if (!have_next) break;

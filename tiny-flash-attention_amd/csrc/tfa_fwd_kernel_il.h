@@ -32,6 +32,9 @@ constexpr int VF_IL_EPI = 262144;        // 16-bit O leaves through a separate L
 constexpr int VF_IL_EPI_INPLACE = 1048576;   // with EPI: the epilogue slices live in the (idle) tile buffers instead of a separate
                                              // region — 64 KiB total, so two 4-wave workgroups still fit a CU
 constexpr int VF_IL_PREF = 524288;       // the next pass's K(0)/V(0)/K(1)/Q are requested BEFORE this pass's epilogue
+constexpr int VF_IL_SEAM = 2097152;      // causal pairs: the heavy pass's last two iterations already request the light pass's K(0), K(1), V(0)
+                                         // (same head, same K/V: the tile stream simply continues across the seam) and its Q
+                                         // fragments are requested before the epilogue: the second prologue finds everything on chip
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
                                          // so the two waves of a SIMD never sit in an LDS-DMA issue stall at the same time
 
@@ -206,14 +209,15 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     {
       const int row = pc * (1024 / (D * 2)) + lane / CPR;
       const int cpos = lane % CPR;
-      k_src[i] = row * (int)p.ks_n * 2 + ((cpos ^ k_swz<D>(row)) << 4);
+      const int kch = cpos ^ k_swz<D>(row);            // source chunk of this lane; chunks beyond the valid head dim read as zeros
+      k_src[i] = kch * 8 < p.dv ? row * (int)p.ks_n * 2 + (kch << 4) : (int)TFA_OOB;
     }
     {
       const int o = pc * 1024 + lane * 16;
       const int sub = o >> 9, R = (o >> 6) & 7, pcs = (o >> 4) & 3;
       const int dt = sub % DT, sh = sub / DT;
       const int key = 16 * (sh >> 1) + 4 * (sh & 1) + 8 * (R >> 2) + (R & 3);
-      v_src[i] = key * (int)p.vs_n * 2 + ((dt * 4 + pcs) << 4);
+      v_src[i] = (dt * 4 + pcs) * 8 < p.dv ? key * (int)p.vs_n * 2 + ((dt * 4 + pcs) << 4) : (int)TFA_OOB;
     }
   }
   const int k_tile_stride = BN * (int)p.ks_n * 2;
@@ -247,13 +251,17 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const int npass = PAIR ? ((p.nmb - 1 - wi) != wi ? 2 : 1) : 1;
   constexpr bool EPI = (VF & VF_IL_EPI) != 0;
   constexpr bool PREF = (VF & VF_IL_PREF) != 0;
+  constexpr bool SEAM = PAIR && (VF & VF_IL_SEAM) != 0;
+  static_assert(!(SEAM && PREF), "SEAM includes the Q prefetch");
+  static_assert(!(SEAM && (VF & VF_IL_EPI_INPLACE)), "the in-place epilogue would overwrite the streamed tiles");
+  bool seam_in = false;                              // this pass's first tiles and Q were requested by the previous pass
   X8 qf[DS];
   auto block_of = [&](int pass) -> int {
     if (PAIR) return pass == 0 ? (p.nmb - 1 - wi) : wi;
     return CAUSAL ? (p.nmb - 1 - wi) : wi;
   };
   // requests for the start of query block mbx: K(0), V(0), K(1) by LDS-DMA and this lane's Q fragments
-  auto issue_prologue = [&](int mbx) {
+  auto issue_prologue = [&](int mbx, bool with_dma) {
     const int q0x = mbx * BM;
     int kve = p.Nk;
     if (CAUSAL) {
@@ -261,19 +269,21 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       kve = lim < kve ? lim : kve;
     }
     const int ntx = kve > 0 ? (kve + BN - 1) / BN : 0;
-    if (ntx > 0) dma_k(0, 0);
-    if (ntx > 0) dma_v(0, 0);
-    if (ntx > 1) dma_k(1, 1);
+    if (with_dma && ntx > 0) dma_k(0, 0);
+    if (with_dma && ntx > 0) dma_v(0, 0);
+    if (with_dma && ntx > 1) dma_k(1, 1);
     const int qoff = (q0x + wave * 32 + qi) * (int)p.qs_n * 2 + hi * 16;
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
-      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, qoff + s * 32, 0, 0);
+      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, (2 * s + hi) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB, 0, 0);
       qf[s] = __builtin_bit_cast(X8, t);
     }
   };
+  const int tr_pass = (p.dbg & 128) ? 1 : 0;
 #pragma nounroll
   for (int pass = 0; pass < npass; ++pass) {
     const int mb = block_of(pass);
+    if (p.trace && pass == 1 && tr_pass == 1) t_start = __builtin_amdgcn_s_memtime();
     const int q0 = mb * BM;
     int kv_end = p.Nk;
     if (CAUSAL) {
@@ -390,14 +400,17 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     };
 
     // ---- prologue: K(0), V(0), K(1) by DMA, Q fragments, S(0) and its row max -------------------------
-    if (!PREF || pass == 0) issue_prologue(mb);      // (with PREF the previous pass already asked for this block)
+    if (SEAM && seam_in) { /* the previous pass streamed K(0), K(1), V(0) and asked for Q */ }
+    else if (!PREF || pass == 0) issue_prologue(mb, true);      // (with PREF the previous pass already asked for this block)
+    // this pass continues its tile stream into the next one when there is one and the buffer parities line up (nt even)
+    const bool seam = SEAM && (pass + 1 < npass) && ((nt & 1) == 0) && nt >= 2;
     o_zero<DT>();
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));
     asm volatile("s_barrier" ::: "memory");
-    if (p.trace && pass == 0) t_pro = __builtin_amdgcn_s_memtime();
+    if (p.trace && pass == tr_pass) t_pro = __builtin_amdgcn_s_memtime();
 
     // tiles this wave computes: 0 .. nact-1 (causal: the waves of a block stop at different tiles)
     const int nact = (wave_last_tile + 1 < nt) ? (wave_last_tile + 1) : nt;
@@ -461,9 +474,10 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       constexpr bool SPREAD = (VF & VF_IL_DMASPREAD) != 0;
       constexpr bool STAGGER = SPREAD && (VF & VF_IL_DMASTAGGER) != 0;
       const bool late = STAGGER && wave >= NW / 2;
-      const bool issue_k = (j + 2 < nt);
+      const bool issue_k = (j + 2 < nt) || seam;         // beyond the last tile: the next pass's K(0) / K(1)
+      const int tk = (j + 2 < nt) ? j + 2 : j + 2 - nt;
       if (!SPREAD && !(AB & ILAB_NODMA)) {
-        if (issue_k) dma_k(j + 2, PAR);
+        if (issue_k) dma_k(tk, PAR);
         dma_v(j + 1, PAR ^ 1);
       }
       const float msc = mref;
@@ -515,7 +529,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         }
         if (SPREAD && !(AB & ILAB_NODMA) && !(STAGGER && late)) {   // 2*PPW DMA pieces spread over the first MFMAs, one per MFMA
           if (i < PPW) dma_v1(j + 1, PAR ^ 1, i);
-          else if (i < 2 * PPW) { if (issue_k) dma_k1(j + 2, PAR, i - PPW); }
+          else if (i < 2 * PPW) { if (issue_k) dma_k1(tk, PAR, i - PPW); }
         }
         soft_slot(i);
         __builtin_amdgcn_sched_barrier(0);
@@ -536,7 +550,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         else asm volatile("" ::"v"(vf[i]), "v"(pw[(i / DT) * 4]), "v"(pw[(i / DT) * 4 + 1]), "v"(pw[(i / DT) * 4 + 2]), "v"(pw[(i / DT) * 4 + 3]));
         if (STAGGER && late && !(AB & ILAB_NODMA)) {
           if (i < PPW) dma_v1(j + 1, PAR ^ 1, i);
-          else if (i < 2 * PPW) { if (issue_k) dma_k1(j + 2, PAR, i - PPW); }
+          else if (i < 2 * PPW) { if (issue_k) dma_k1(tk, PAR, i - PPW); }
         }
         soft_slot(N1 + i);
 #pragma unroll
@@ -556,7 +570,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       const int par = j & 1;
       ++n_slow;
       if (j + 2 < nt) dma_k(j + 2, par);
+      else if (seam) dma_k(j + 2 - nt, par);
       if (j + 1 < nt) dma_v(j + 1, par ^ 1);
+      else if (seam) dma_v(0, par ^ 1);
       rescale_if_needed(mcur);
       const float msc = mref;
       const char* vbp = vl + par * TILE_BYTES;
@@ -596,15 +612,18 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #pragma nounroll
     for (int j = nact; j < nt; ++j) {                    // tiles of the block this wave does not touch
       if (j + 2 < nt) dma_k(j + 2, j & 1);
+      else if (seam) dma_k(j + 2 - nt, j & 1);
       if (j + 1 < nt) dma_v(j + 1, (j & 1) ^ 1);
+      else if (seam) dma_v(0, (j & 1) ^ 1);
       iter_end();
     }
-    if (p.trace && pass == 0) t_loop = __builtin_amdgcn_s_memtime();
+    if (p.trace && pass == tr_pass) t_loop = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue ---------------------------------------------------------------------------
     // every wave is past the last tile's barrier: the K/V buffers and qf are free -> ask for the next pass's first tiles
     // and Q now, so that their latency hides behind the normalisation and the stores below
-    if (PREF && pass + 1 < npass) issue_prologue(block_of(pass + 1));
+    if (PREF && pass + 1 < npass) issue_prologue(block_of(pass + 1), true);
+    if (SEAM) { seam_in = seam; if (seam) issue_prologue(block_of(pass + 1), false); }   // Q only: K(0), K(1), V(0) are on chip
     const float l_tot = pair_sum((l4[0] + l4[1]) + (l4[2] + l4[3]));
     const bool empty = !(l_tot > 0.f);
     const float inv = empty ? 1.f : 1.f / l_tot;
@@ -623,7 +642,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4 v4 = {o[4 * g + 0], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, ooff + (d * 32 + g * 8) * 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, d * 32 + g * 8 + hi * 4 < p.dv ? ooff + (d * 32 + g * 8) * 4 : (int)TFA_OOB, 0, 0);
         }
       }
     } else if (EPI) {
@@ -661,7 +680,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         const int r = i * RPI + lanex / CH, cpos = lanex % CH;
         const int c = cpos ^ ((CH == 16) ? (r & 15) : (r & 7));
         u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
-        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, (wave_row0 + r) * (int)p.os_n * 2 + (c << 4), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, 0);
       }
       if (INPLACE) {
         // the next pass's first DMA pieces land in these buffers: every wave must have read its rows back
@@ -681,7 +700,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           t4 v4 = {(T)o[4 * g + 0], (T)o[4 * g + 1], (T)o[4 * g + 2], (T)o[4 * g + 3]};
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, ooff + (d * 32 + g * 8) * 2, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, d * 32 + g * 8 + hi * 4 < p.dv ? ooff + (d * 32 + g * 8) * 2 : (int)TFA_OOB, 0, 0);
         }
       }
     }

@@ -197,14 +197,15 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     {
       const int row = pc * (1024 / (D * 2)) + lane / CPR;
       const int cpos = lane % CPR;
-      k_src[i] = row * (int)p.ks_n * 2 + ((cpos ^ k_swz<D>(row)) << 4);
+      const int kch = cpos ^ k_swz<D>(row);            // source chunk of this lane; chunks beyond the valid head dim read as zeros
+      k_src[i] = kch * 8 < p.dv ? row * (int)p.ks_n * 2 + (kch << 4) : (int)TFA_OOB;
     }
     {
       const int o = pc * 1024 + lane * 16;
       const int sub = o >> 9, R = (o >> 6) & 7, pcs = (o >> 4) & 3;
       const int dt = sub % DT, sh = sub / DT;
       const int key = 16 * (sh >> 1) + 4 * (sh & 1) + 8 * (R >> 2) + (R & 3);
-      v_src[i] = key * (int)p.vs_n * 2 + ((dt * 4 + pcs) << 4);
+      v_src[i] = (dt * 4 + pcs) * 8 < p.dv ? key * (int)p.vs_n * 2 + ((dt * 4 + pcs) << 4) : (int)TFA_OOB;
     }
   }
   const int k_tile_stride = BN * (int)p.ks_n * 2;
@@ -228,7 +229,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
   const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
   const float sc = p.scale_log2;
-  int nt_total = 0, n_slow = 0;
+  int nt_total = 0, n_slow = 0, n_trig = 0;
+  const int dbg = p.dbg;                          // debug flags (tfa_debug_set_flags; 0 in normal use): see the uses below
+  auto big_fence = [&]() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
 
   typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
   auto k_frag = [&](unsigned kboff, int i) -> X8 {
@@ -248,9 +251,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     return CAUSAL ? (p.nmb - 1 - wi) : wi;
   };
 
+  const int tr_pass = (p.dbg & 128) ? 1 : 0;
 #pragma nounroll
   for (int pass = 0; pass < npass; ++pass) {
     const int mb = block_of(pass);
+    if (p.trace && pass == 1 && tr_pass == 1) t_start = __builtin_amdgcn_s_memtime();
     const int q0 = mb * BM;
     int kv_end = p.Nk;
     if (CAUSAL) {
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       for (int rb = 0; rb < RB; ++rb) {
         const int qoff = (wave_row0 + rb * 32 + qi) * (int)p.qs_n * 2 + hi * 16;
 #pragma unroll
-        for (int s = 0; s < DS; ++s) qv[rb][s] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, qoff + s * 32, 0, 0);
+        for (int s = 0; s < DS; ++s) qv[rb][s] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, (2 * s + hi) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB, 0, 0);
       }
       x4_o_fence();                                    // (second pass: the previous epilogue's reads of O are long done; cheap)
       x4_o_zero();
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     }
 
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (p.trace && pass == 0) t_pro = __builtin_amdgcn_s_memtime();
+    if (p.trace && pass == tr_pass) t_pro = __builtin_amdgcn_s_memtime();
 
     // tiles this wave computes: 0 .. nact-1 (causal: the waves of a block stop at different tiles)
     const int wave_last_tile = CAUSAL ? ((wave_row0 + 32 * RB - 1 + shift) >= 0 ? (wave_row0 + 32 * RB - 1 + shift) / BN : -1) : (nt - 1);
@@ -391,6 +396,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
           else M::template qk<X4_QBASE + 4 * (rb * DS + (i >> 1))>(s[rb][i & 1], kf);
         });
       });
+      if (dbg & 8) big_fence();
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         x4_fence_v(s[rb][0]);
@@ -439,6 +445,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       X8 kf[NKF], vf[NVF];
 #pragma unroll
       for (int i = 0; i < PF; ++i) kf[i] = kpre[i];
+      // The prefetched fragments are loop-carried compiler values: under register pressure hipcc parks them in AGPRs and
+      // restores them (v_accvgpr_read = a VALU write) right in front of the first S MFMA, which — being an asm — it does
+      // not pad: the MFMA then reads stale registers (row block 0 only, data-dependent on timing).  Pin them here, two
+      // wait states ahead.  tools/audit_mfma_hazard.py checks every MFMA of the generated assembly for this at build time.
+      static_assert(PF == 2 || PF == 3, "pin list below");
+      if constexpr (PF == 2) asm volatile("s_nop 1" : "+v"(kf[0]), "+v"(kf[1]));
+      else asm volatile("s_nop 1" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]));
       // the softmax work of MFMA slot g, issued in this order behind the MFMA: scale/subtract (independent of everything
       // recent), then sum + pack of the elements exponentiated in the PREVIOUS slot, then this slot's exponentials.  A
       // transcendental result needs one wait state before a VALU instruction reads it, and hipcc counts an asm MFMA as
@@ -467,15 +480,19 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         }
       };
       // DMA piece n of this iteration (V(j+1) pieces 0..PPW-1, then K(j+3)) goes behind MFMA slot DMA0 + n * DMASTEP.  When
-      // K(j+3) does not exist the piece is still issued, with an out-of-range offset (the descriptor's bounds check turns
-      // it into a no-op read): no branch in the tile body.
-      const int k_tile_off = issue_k ? (j + 3) * k_tile_stride : 0x7f000000;
+      // K(j+3) does not exist the piece is still issued, with an out-of-range offset (the descriptor's bounds check makes
+      // it read zeros into a buffer nobody reads again): one v_cndmask instead of a branch in the tile body.
+      const int k_tile_off = (j + 3) * k_tile_stride;
       auto dma_slot = [&](auto g_c) {
         constexpr int g = decltype(g_c)::value;
         if constexpr (!(AB & X4AB_NODMA) && g >= TFA_X4_DMA0 && (g - TFA_X4_DMA0) % TFA_X4_DMASTEP == 0 && (g - TFA_X4_DMA0) / TFA_X4_DMASTEP < 2 * PPW) {
           constexpr int n = (g - TFA_X4_DMA0) / TFA_X4_DMASTEP;
           if constexpr (n < PPW) dma_v1(j + 1, PAR ^ 1, n);
-          else lds_dma16_m0(k_rs, my_piece0 + kb0 + (n - PPW) * 1024, k_src[n - PPW] + k_tile_off);
+#if defined(TFA_X4_BRANCHY_K)
+          else { if (issue_k) lds_dma16_m0(k_rs, my_piece0 + kb0 + (n - PPW) * 1024, k_src[n - PPW] + (j + 3) * k_tile_stride); }
+#else
+          else lds_dma16_m0(k_rs, my_piece0 + kb0 + (n - PPW) * 1024, issue_k ? k_src[n - PPW] + k_tile_off : (int)TFA_OOB);
+#endif
         }
       };
       static_assert(TFA_X4_DMA0 + (2 * PPW - 1) * TFA_X4_DMASTEP < N1 + N2, "a DMA piece falls behind the last MFMA slot");
@@ -505,8 +522,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         constexpr int g = decltype(g_c)::value, i = g >> 1, rb = g & 1;
         if constexpr (rb == 0) {
           if constexpr (i + PF < NVF) vf[i + PF] = (AB & X4AB_NOVREAD) ? vf[i % PF] : v_frag(vbp, i + PF);
-          else kpre[i + PF - NVF] = k_frag(kb2, i + PF - NVF);   // K(j+2) landed before the previous barrier (read even when no
-                                                                 // later iteration wants it: stale LDS bytes, never used — no branch)
+#if defined(TFA_X4_BRANCHY_KPRE)
+          else { if (j + 2 < nact) kpre[i + PF - NVF] = k_frag(kb2, i + PF - NVF); }
+#else
+          else kpre[i + PF - NVF] = k_frag(kb2, i + PF - NVF);   // K(j+2) landed before the previous barrier (read even when no later
+#endif                                                           // iteration wants it: stale LDS bytes, never used — no branch)
         }
         if constexpr (!(AB & X4AB_NOPV)) M::template pv<(rb * DT + i % DT) * 16>(vf[i], p_frag(pw, rb, i / DT));
         else asm volatile("" ::"v"(vf[i]), "v"(pw[rb][(i / DT) * 4]), "v"(pw[rb][(i / DT) * 4 + 1]), "v"(pw[rb][(i / DT) * 4 + 2]), "v"(pw[rb][(i / DT) * 4 + 3]));
@@ -526,12 +546,14 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       });
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) mnext[rb] = (AB & X4AB_NOMAX) ? snext[rb][0][0] * 1e-30f : mx[rb];
+      if (dbg & 16) big_fence();
       iter_end();
     };
     // ---- slow path: any tile (masked successor, last, re-base needed), burst-structured -------------------------------
     auto slow = [&](int j, f32x16 (&scur)[RB][2], const float (&mcur)[RB], f32x16 (&snext)[RB][2], float (&mnext)[RB]) {
       const int par = j & 1;
       ++n_slow;
+      if (dbg & 2) big_fence();
       if (j + 3 < nt) dma_k(j + 3, kb0);
       if (j + 1 < nt) dma_v(j + 1, par ^ 1);
       const char* vbp = vl + par * TILE_BYTES;
@@ -556,11 +578,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         const X8 vfr = v_frag(vbp, i);
         X8 p0 = p_frag(pw, 0, i / DT), p1 = p_frag(pw, 1, i / DT);
         asm volatile("s_nop 1" : "+v"(p0), "+v"(p1));    // VALU write -> MFMA operand: 2 wait states
+        if (dbg & 4) big_fence();
         M::template pv<(0 * DT + i % DT) * 16>(vfr, p0);
         M::template pv<(1 * DT + i % DT) * 16>(vfr, p1);
       });
       if (j + 1 < nact) qk_burst(kb1, j + 1, snext, mnext);
-      if (j + 2 < nact) load_kpre(kb2);
+      if (!(dbg & 32) && j + 2 < nact) load_kpre(kb2);
       iter_end();
     };
 
@@ -571,12 +594,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     using C1 = std::integral_constant<int, 1>;
 #pragma nounroll
     for (int j = 0; j < nact; j += 2) {
-      if (j + 1 < fm && j + 1 < nact && !trigger(mA)) fused(C0{}, j, sA, sB, mB);
-      else slow(j, sA, mA, sB, mB);
+      if (!(dbg & 1) && j + 1 < fm && j + 1 < nact && !trigger(mA)) fused(C0{}, j, sA, sB, mB);
+      else { if (p.trace && j + 1 < fm && j + 1 < nact) ++n_trig; slow(j, sA, mA, sB, mB); }
       rotate();
       if (j + 1 >= nact) break;
-      if (j + 2 < fm && j + 2 < nact && !trigger(mB)) fused(C1{}, j + 1, sB, sA, mA);
-      else slow(j + 1, sB, mB, sA, mA);
+      if (!(dbg & 1) && j + 2 < fm && j + 2 < nact && !trigger(mB)) fused(C1{}, j + 1, sB, sA, mA);
+      else { if (p.trace && j + 2 < fm && j + 2 < nact) ++n_trig; slow(j + 1, sB, mB, sA, mA); }
       rotate();
     }
 #pragma nounroll
@@ -586,9 +609,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       iter_end();
       rotate();
     }
-    if (p.trace && pass == 0) t_loop = __builtin_amdgcn_s_memtime();
+    if (p.trace && pass == tr_pass) t_loop = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
+    if (dbg & 64) big_fence();
     x4_o_fence();
     static_for<0, RB>([&](auto rb_c) {
       constexpr int rb = decltype(rb_c)::value;
@@ -607,7 +631,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         static_for<0, DT * 4>([&](auto c_c) {
           constexpr int c = decltype(c_c)::value, R = (rb * DT + c / 4) * 16 + (c % 4) * 4;
           f32x4 v4 = {x4_o_read<R>() * inv, x4_o_read<R + 1>() * inv, x4_o_read<R + 2>() * inv, x4_o_read<R + 3>() * inv};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, ooff + ((c / 4) * 32 + (c % 4) * 8) * 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, (c / 4) * 32 + (c % 4) * 8 + hi * 4 < p.dv ? ooff + ((c / 4) * 32 + (c % 4) * 8) * 4 : (int)TFA_OOB, 0, 0);
         });
       } else if constexpr (EPI) {
         // A lane holds 4-element pieces of ONE row in 16 register groups: stored directly that is 16 eight-byte stores per
@@ -633,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
           const int r = i * RPI + lanex / CH, cpos = lanex % CH;
           const int c = cpos ^ ((CH == 16) ? (r & 15) : (r & 7));
           u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
-          __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, (wave_row0 + rb * 32 + r) * (int)p.os_n * 2 + (c << 4), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 + rb * 32 + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by this wave's next epilogue only
       } else {
@@ -644,7 +668,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         static_for<0, DT * 4>([&](auto c_c) {
           constexpr int c = decltype(c_c)::value, R = (rb * DT + c / 4) * 16 + (c % 4) * 4;
           t4 v4 = {(T)(x4_o_read<R>() * inv), (T)(x4_o_read<R + 1>() * inv), (T)(x4_o_read<R + 2>() * inv), (T)(x4_o_read<R + 3>() * inv)};
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, ooff + ((c / 4) * 32 + (c % 4) * 8) * 2, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, (c / 4) * 32 + (c % 4) * 8 + hi * 4 < p.dv ? ooff + ((c / 4) * 32 + (c % 4) * 8) * 2 : (int)TFA_OOB, 0, 0);
         });
       }
     });
@@ -658,7 +682,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     if (tid == 0) {
       unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
       t[0] = t_start; t[1] = t_pro; t[2] = t_loop; t[3] = t_end;
-      t[4] = (unsigned long long)nt_total | ((unsigned long long)n_slow << 32);   // wave 0's slow-path tiles in the high half
+      t[4] = (unsigned long long)nt_total | ((unsigned long long)n_slow << 32) | ((unsigned long long)n_trig << 48);   // wave 0: slow-path tiles, of which re-base triggers
       t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63508) | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32);   // XCC_ID | HW_ID << 32
       t[6] = __builtin_amdgcn_s_memrealtime() - rt_start;   // 100 MHz ticks over the same span as t[3] - t[0] shader cycles
       t[7] = ((unsigned long long)bh << 32) | (unsigned)wi;

@@ -60,11 +60,13 @@ static const Variant kVariants[] = {
     {"il8-pair-dmaspread-epi-pref (+ the next pass's first tiles and Q requested before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF, 1},
     {"il4-pair-epi (4 waves x2 workgroups per CU; O leaves through the idle tile buffers as whole rows)", 4, VF_DMA | VF_IL | VF_PAIR | VF_IL_EPI | VF_IL_EPI_INPLACE, 1},
     {"il-x4-pair-epi (issue-interleaved, 4 waves x 64 rows: one wave per SIMD, O and Q in AGPRs, K ring of three LDS buffers)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR | VF_X4_EPI, 2},
+    {"il8-pair-dmaspread-epi-seam (variant 30 + the heavy pass's last tiles stream the light pass's K(0), K(1), V(0); Q before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_SEAM, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
 constexpr int kSmallGridVariant = 32;     // il4-pair-epi (128-row query blocks, two workgroups per CU)
 constexpr int kX4Variant = 33;            // il-x4-pair-epi
+constexpr int kSeamVariant = 34;          // il8-pair-dmaspread-epi-seam
 constexpr int kSplitVariant = 17;         // dma4-pair-2buf: the kernel whose grid can carry key chunks (tfa_fwd_splitkv)
 
 struct LaunchGeom {
@@ -80,7 +82,7 @@ static inline bool variant_built(int variant) {
 #if defined(TFA_EXPERIMENTAL)
   return true;
 #else
-  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant || variant == kX4Variant;
+  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant || variant == kX4Variant || variant == kSeamVariant;
 #endif
 }
 
@@ -101,6 +103,14 @@ static inline hipError_t launch_common(Kern kern, std::atomic<unsigned long long
 // defined in tfa_x4_inst_<dtype>_<D>.hip; ablate != 0 selects a timing-only ablation (EXPERIMENTAL builds)
 template <typename T, int D>
 hipError_t launch_x4_unit(const KArgs& a, bool causal, bool f32out, int ablate, hipStream_t stream, LaunchGeom* geom, bool dry);
+
+// kernels that honour KArgs::dv (head dims below the compiled width: LDS-DMA lanes / Q loads / O stores of the missing
+// 16-byte chunks go out of range): the LDS-DMA kernel, the il kernels and the x4 kernel
+static inline bool supports_padded_d(int variant) {
+  if (variant < 0 || variant >= kNumVariants) return false;
+  const int vf = kVariants[variant].vf;
+  return (vf & VF_DMA) && !(vf & (VF_SWP | VF_W64));
+}
 
 static inline int block_m_of(int variant) { return kVariants[variant].nw * 32 * kVariants[variant].rb; }
 static inline bool uses_dma(int variant) { return (kVariants[variant].vf & VF_DMA) != 0; }

@@ -1,0 +1,52 @@
+"""Interleaved A/B of several BUILDS of the library in one process (same inputs, same box, round-robin):
+usage: python tools/ab_multi.py name=path[:variant] ... [--cfgs cfg3,cfg4] [--rounds 5] [--iters 30]
+Each entry loads its own copy of libtfa_hip.so with ctypes; `variant` defaults to 33 (the x4 kernel)."""
+import argparse, ctypes as C, math, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tiny_flash_attention_amd import _lib, ops
+CFG = {"cfg2": (4, 8, 1024, 64, torch.float16, False), "cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096, 128, torch.bfloat16, False),
+       "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg4c": (1, 16, 16384, 128, torch.bfloat16, True), "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),
+       "n2k": (8, 32, 2048, 128, torch.bfloat16, True), "n1k": (16, 32, 1024, 128, torch.bfloat16, True), "d64": (4, 32, 4096, 64, torch.float16, False),
+       "d64c": (4, 32, 4096, 64, torch.float16, True)}
+ap = argparse.ArgumentParser()
+ap.add_argument("libs", nargs="+")
+ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4")
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--warm", type=float, default=1.0)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+P = C.POINTER(_lib.TfaFwdParams)
+entries = []
+for spec in a.libs:
+    name, rest = spec.split("=", 1)
+    path, _, var = rest.partition(":")
+    L = C.CDLL(os.path.abspath(path))
+    L.tfa_fwd_time.argtypes = [P, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+    L.tfa_set_variant.argtypes = [C.c_int]
+    entries.append((name, L, int(var) if var else 33))
+for cfg in a.cfgs.split(","):
+    B, H, N, D, dt, causal = CFG[cfg]
+    mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(dt)
+    q, k, v = mk(), mk(), mk()
+    out = torch.empty_like(q); lse = torch.empty((B, H, N), dtype=torch.float32, device=dev)
+    p = ops.make_params(q, k, v, out, lse, causal, 1 / math.sqrt(D))
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fl, by = C.c_double(), C.c_double()
+    _lib.lib().tfa_fwd_work(C.byref(p), C.byref(fl), C.byref(by))
+    ms = C.c_float()
+    t0 = time.time()
+    name, L, var = entries[0]
+    assert L.tfa_set_variant(var) == 0, (name, var)
+    while time.time() - t0 < a.warm:
+        assert L.tfa_fwd_time(C.byref(p), 0, 50, s, C.byref(ms)) == 0
+    res = {e[0]: [] for e in entries}
+    for r in range(a.rounds):
+        for name, L, var in entries:
+            assert L.tfa_set_variant(var) == 0, (name, var)
+            st = L.tfa_fwd_time(C.byref(p), 3, a.iters, s, C.byref(ms))
+            assert st == 0, (name, st)
+            res[name].append(fl.value / (ms.value * 1e-3) / 1e12)
+    print(f"{cfg:7s}", "  ".join(f"{n}: {sorted(x)[len(x) // 2]:7.1f}" for n, x in res.items()), flush=True)

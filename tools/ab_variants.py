@@ -15,6 +15,9 @@ ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--warm", type=float, default=1.0, help="seconds of pre-conditioning launches before the rounds")
+ap.add_argument("--data", default="normal", choices=["normal", "zeros", "ones", "small"],
+                help="input values: the reference's normal(0,0.5), all zeros, all ones, or normal(0,0.01) — same instruction stream, "
+                     "different switching activity (the DVFS give-back experiment of MI355X_MICROARCH.md)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 L = _lib.lib()
@@ -22,7 +25,14 @@ vs = [int(x) for x in a.variants.split(",")]
 import time
 for cfg in a.cfgs.split(","):
     B, H, N, D, dt, causal = CFG[cfg]
-    mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(dt)
+    if a.data == "normal":
+        mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(dt)
+    elif a.data == "small":
+        mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0, 0.01).to(dt)
+    elif a.data == "zeros":
+        mk = lambda: torch.zeros((B, H, N, D), dtype=dt, device=dev)
+    else:
+        mk = lambda: torch.ones((B, H, N, D), dtype=dt, device=dev)
     q, k, v = mk(), mk(), mk()
     out = torch.empty_like(q); lse = torch.empty((B, H, N), dtype=torch.float32, device=dev)
     p = ops.make_params(q, k, v, out, lse, causal, 1 / math.sqrt(D))
@@ -41,4 +51,4 @@ for cfg in a.cfgs.split(","):
             _lib.check(L.tfa_fwd_time(C.byref(p), 3, a.iters, s, C.byref(ms)))
             res[vv].append(fl.value / (ms.value * 1e-3) / 1e12)
     _lib.set_variant(-1)
-    print(cfg, " ".join(f"v{vv}: med {sorted(res[vv])[len(res[vv]) // 2]:7.1f} max {max(res[vv]):7.1f} TF" for vv in vs), flush=True)
+    print(cfg, f"[{a.data}]", " ".join(f"v{vv}: med {sorted(res[vv])[len(res[vv]) // 2]:7.1f} max {max(res[vv]):7.1f} TF" for vv in vs), flush=True)

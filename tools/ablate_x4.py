@@ -17,7 +17,7 @@ p = ops.make_params(q, k, v, out, lse, False, 1 / math.sqrt(D))
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 L = _lib.lib()
 tiles_per_wg = N // 64
-masks = [0, 1, 2, 4, 8, 9, 192, 64, 128, 201, 240, 6, 15, 207]
+masks = [0, 1, 2, 4, 8, 192, 201, 6, 15, 207]
 if len(sys.argv) > 1:
     masks = [int(x) for x in sys.argv[1].split(",")]
 base = int(os.environ.get("ABL_BASE", "3000"))

@@ -54,9 +54,15 @@ def trace(variant, cfg):
         st[m] = t[m, 0] - b0
         en[m] = t[m, 3] - b0
     pro, loop, epi, nt = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] & 0xFFFFFFFF
-    nslow = t[:, 4] >> 32
+    nslow = (t[:, 4] >> 32) & 0xFFFF
+    ntrig = (t[:, 4] >> 48) & 0xFFFF
     if nslow.max() > 0:
-        print(f"slow-path tiles of wave 0 per workgroup: mean {nslow.mean():.2f} max {nslow.max()} (of {nt.mean():.1f} tiles)")
+        print(f"slow-path tiles of wave 0 per workgroup: mean {nslow.mean():.2f} max {nslow.max()} (of {nt.mean():.1f} tiles); of those re-base triggers: mean {ntrig.mean():.2f} max {ntrig.max()}")
+        if os.environ.get("DUMP_SLOW"):
+            wi_ = t[:, 7] & 0xFFFFFFFF
+            for w in np.unique(wi_):
+                m = wi_ == w
+                print(f"    work item {w}: tiles {nt[m].mean():.0f} slow {nslow[m].mean():.1f} trig {ntrig[m].mean():.1f}")
     span = en.max()
     print(f"== variant {variant} {_lib.variant_name(variant)} | {cfg}: grid {g.value} block {b.value}")
     print(f"kernel span {span} cycles (max over XCCs of last end - first start); prologue mean {pro.mean():.0f} "
