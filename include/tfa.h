@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 103 /* 0.1.3: forward head dims = every multiple of 8 up to 128; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
+#define TFA_VERSION 103 /* 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
 
 /* element types */
 enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1, TFA_F32 = 2 /* output only */ };
@@ -66,7 +66,7 @@ enum tfa_status {
   TFA_OK = 0,
   TFA_ERR_NULL = -1,          /* a required pointer is NULL */
   TFA_ERR_DTYPE = -2,         /* dtype not in {F16,BF16}; out_dtype not in {dtype,F32} */
-  TFA_ERR_HEAD_DIM = -3,      /* forward: D not a multiple of 8 in [8,128]; split-KV / merge / backward: D not in {64,128} */
+  TFA_ERR_HEAD_DIM = -3,      /* forward: D not a multiple of 8 in [8,256]; split-KV / merge / backward: D not in {64,128} */
   TFA_ERR_SHAPE = -4,         /* B,H,Hk,Nq,Nk <= 0 or H % Hk != 0 */
   TFA_ERR_STRIDE = -5,        /* a stride is negative, not 16-byte aligned, or a (b,h) slice reaches 2 GiB */
   TFA_ERR_ALIGN = -6,         /* a base pointer is not 16-byte aligned */

@@ -84,7 +84,7 @@ def test_product_build_rejects_ab_arms():
     # the product library carries the dispatched kernels only (tfa_launch.h); the other table entries answer TFA_ERR_VARIANT
     L = _lib.lib()
     avail = [v for v in range(_lib.num_variants()) if _lib.variant_available(v)]
-    for v in (17, 30, 32):
+    for v in (17, 30, 32, 33, 34):
         assert v in avail
     for v in range(_lib.num_variants()):
         if v not in avail:
@@ -98,8 +98,10 @@ def test_rejects_bad_descriptors():
     cases.append((_params(dtype=2), -2))
     cases.append((_params(out_dtype=0), -2))           # bf16 in, f16 out
     cases.append((_params(D=100), -3))                 # not a multiple of 8
-    cases.append((_params(D=136), -3))                 # beyond the 128-wide kernel (the reference's 160..256 buckets)
+    cases.append((_params(D=264), -3))                 # beyond the widest kernel
     assert plan(_params(D=96))[0] == 0 and plan(_params(D=32, dtype=_lib.TFA_F16))[0] == 0 and plan(_params(D=8))[0] == 0
+    st, grid, block, lds = plan(_params(B=2, H=4, Hk=4, Nq=1024, Nk=1024, D=256))   # x4-d256: 128-row blocks paired, five 32 KiB tile buffers
+    assert st == 0 and block == 256 and grid == 2 * 4 * 4 and lds == 5 * 64 * 256 * 2
     cases.append((_params(Nq=0), -4))
     cases.append((_params(H=6, Hk=4), -4))
     p = _params(); p.k_stride[2] = 100; cases.append((p, -5))   # row stride not 16-byte aligned

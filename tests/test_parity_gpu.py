@@ -117,7 +117,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29, 30, 31, 32, 33, 34])
+@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29, 30, 31, 32, 33, 35])
 @pytest.mark.parametrize("dtype,B,H,N,D,causal", SHAPES)
 def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
     from tiny_flash_attention_amd import _lib
@@ -130,7 +130,7 @@ def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causa
         _lib.set_variant(-1)
 
 
-@pytest.mark.parametrize("variant", [-1, 17, 30, 31, 33, 34])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
+@pytest.mark.parametrize("variant", [-1, 17, 30, 31, 33, 35])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
 @pytest.mark.parametrize("Nq,Nk,causal", [(128, 384, True), (384, 128, True), (100, 333, False), (1, 1000, True), (257, 64, False),
                                           (700, 1500, True), (1111, 1111, False)])
 def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
@@ -169,6 +169,39 @@ def test_head_dims_below_the_kernel_width(tfa, oracle, dev, variant, dtype, B, H
         run_case(tfa, oracle, dev, dtype, B, H, N, D, causal, seed=40 + D)
     finally:
         _lib.set_variant(-1)
+
+
+# head dims above 128: the x4 kernel with one 32-row block per wave (the reference's buckets 160, 192, 224, 256 and its
+# intended benchmark dim 256, flash_attention_cutlass/test.py:44-48); anything between is padded like the dims below 128
+@pytest.mark.parametrize("dtype,B,H,N,D,causal", [
+    (torch.bfloat16, 1, 2, 512, 256, True),
+    (torch.float16, 2, 2, 384, 256, False),
+    (torch.bfloat16, 1, 3, 300, 192, True),      # ragged N, padded D
+    (torch.float16, 1, 2, 256, 160, False),
+    (torch.bfloat16, 2, 1, 1024, 224, True),
+    (torch.bfloat16, 1, 1, 1, 256, True),        # single row
+    (torch.float16, 1, 2, 129, 136, False),
+])
+def test_head_dims_above_128(tfa, oracle, dev, dtype, B, H, N, D, causal):
+    from tiny_flash_attention_amd import _lib
+
+    assert _lib.variant_name(_lib.variant_for(B, H, H, N, N, D, causal)).startswith("x4-d256")
+    run_case(tfa, oracle, dev, dtype, B, H, N, D, causal, seed=50 + D)
+
+
+def test_head_dim_256_gqa_ragged_nq_nk_and_spike(tfa, oracle, dev):
+    from tiny_flash_attention_amd import ops
+
+    run_case(tfa, oracle, dev, torch.bfloat16, 1, 4, 200, 256, True, Hk=2, Nk=456, seed=61)      # bottom-right causal, GQA
+    run_case(tfa, oracle, dev, torch.float16, 1, 2, 384, 256, True, Hk=1, Nk=128, seed=62)       # rows with no visible key
+    q, k, v = oracle.make_inputs(1, 2, 768, 256, torch.bfloat16, seed=63)
+    for (row, key, gain) in ((5, 500, 4.0), (300, 700, 6.0), (37, 767, 8.0)):                    # late max jumps: the re-base path
+        k[0, :, key] = (q[0, :, row].float() * gain).to(torch.bfloat16)
+    sc = 1.0 / math.sqrt(256)
+    for causal in (False, True):
+        out16, lse = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc)
+        out32, _ = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc, out_f32=True)
+        check(oracle, out16, out32, lse, q, k, v, causal, sc, torch.bfloat16)
 
 
 def test_head_dim_96_gqa_strided_and_reference_binding(tfa, oracle, dev):
@@ -272,7 +305,7 @@ def test_inputs_not_modified_and_deterministic(tfa, oracle, dev):
 # ---------------------------------------------------------------------------------------------
 # data-dependent branch: the exact "max unchanged -> skip the O rescale" path and late max jumps
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [1, 2, 5, 10, 11, 14, 15, 17, 18, 19, 20, 22, 26, 27, 28, 30, 31, 32, 33, 34])
+@pytest.mark.parametrize("variant", [1, 2, 5, 10, 11, 14, 15, 17, 18, 19, 20, 22, 26, 27, 28, 30, 31, 32, 33, 35])
 def test_late_max_jump_spike(tfa, oracle, dev, variant):
     from tiny_flash_attention_amd import _lib, ops
 

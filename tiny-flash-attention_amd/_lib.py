@@ -220,4 +220,4 @@ def variant_for(B, H, Hk, Nq, Nk, D, is_causal, dtype=TFA_BF16):
 
 def lazy_reference(v):
     """True for the variants that keep a lazily re-based row reference instead of the exact running max."""
-    return variant_name(v).startswith("il")
+    return variant_name(v).startswith("il") or variant_name(v).startswith("x4")

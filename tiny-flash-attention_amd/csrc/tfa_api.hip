@@ -17,6 +17,9 @@ template <> hipError_t launch_fwd<__bf16, 64>(const KArgs&, bool, bool, int, hip
 template <> hipError_t launch_fwd<__bf16, 128>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
 template <> hipError_t launch_fwd<_Float16, 64>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
 template <> hipError_t launch_fwd<_Float16, 128>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
+// defined in tfa_x4_inst_<dtype>_256.hip: the kernel for head dims above 128
+template <> hipError_t launch_x4_unit<__bf16, 256>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
+template <> hipError_t launch_x4_unit<_Float16, 256>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
 }  // namespace tfa
 
 namespace {
@@ -30,6 +33,7 @@ thread_local int g_dbg_flags = 0;                    // kernel bring-up flags (t
 int num_cus() { return tfa::num_cus_current_device(); }
 
 int pick_variant(const tfa_fwd_params* p) {
+  if (p && p->D > 128) return tfa::kX4D256Variant;   // one kernel serves 136..256 (a forced variant does not apply)
   if (g_variant >= 0) return g_variant;
   if (!p) return tfa::kDefaultVariant;
   // Measured on MI355X (tests/tools/ab.py, profiles/): 256-row query blocks (8 waves) are fastest when there
@@ -61,13 +65,14 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   if (!p->q || !p->k || !p->v || !p->out) return TFA_ERR_NULL;
   if (p->dtype != TFA_F16 && p->dtype != TFA_BF16) return TFA_ERR_DTYPE;
   if (p->out_dtype != p->dtype && p->out_dtype != TFA_F32) return TFA_ERR_DTYPE;
-  if (p->D < 8 || p->D > 128 || (p->D % 8) != 0) return TFA_ERR_HEAD_DIM;   // > 128 (the reference's 160..256 buckets) needs its own kernel
+  if (p->D < 8 || p->D > 256 || (p->D % 8) != 0) return TFA_ERR_HEAD_DIM;
   if (p->B <= 0 || p->H <= 0 || p->Hk <= 0 || p->Nq <= 0 || p->Nk <= 0) return TFA_ERR_SHAPE;
   if (p->H % p->Hk != 0) return TFA_ERR_SHAPE;
   if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
   const bool ablate = (variant >= 100 && variant < 100 + 512) || (variant >= 700 && variant < 716) || (variant >= 1000 && variant < 2256) || (variant >= 3000 && variant < 3256);   // timing-only ablations (debug)
   if (!ablate && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
   if (p->D != 64 && p->D != 128 && (ablate || !tfa::supports_padded_d(variant))) return TFA_ERR_HEAD_DIM;   // (A/B arms: 64 / 128 only)
+  if ((p->D > 128) != (variant == tfa::kX4D256Variant)) return TFA_ERR_HEAD_DIM;
   const int esz = 2, osz = (p->out_dtype == TFA_F32) ? 4 : 2;
   const int64_t* st[4] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride};
   for (int t = 0; t < 4; ++t) {
@@ -122,8 +127,11 @@ int run(const tfa_fwd_params* p, void* stream, tfa::LaunchGeom* geom, bool dry) 
   const bool f32out = p->out_dtype == TFA_F32;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipError_t e;
-  const bool wide = p->D > 64;   // kernel width: 64 serves D <= 64, 128 serves 64 < D <= 128 (KArgs::dv = the valid part)
-  if (p->dtype == TFA_BF16) {
+  const bool wide = p->D > 64;   // kernel width: 64 serves D <= 64, 128 serves 64 < D <= 128, 256 the rest (KArgs::dv = the valid part)
+  if (p->D > 128) {
+    e = (p->dtype == TFA_BF16) ? tfa::launch_x4_unit<__bf16, 256>(a, causal, f32out, 0, s, geom, dry)
+                               : tfa::launch_x4_unit<_Float16, 256>(a, causal, f32out, 0, s, geom, dry);
+  } else if (p->dtype == TFA_BF16) {
     e = wide ? tfa::launch_fwd<__bf16, 128>(a, causal, f32out, variant, s, geom, dry)
              : tfa::launch_fwd<__bf16, 64>(a, causal, f32out, variant, s, geom, dry);
   } else {
@@ -155,7 +163,7 @@ const char* tfa_strerror(int status) {
     case TFA_OK: return "success";
     case TFA_ERR_NULL: return "tfa: a required pointer is NULL";
     case TFA_ERR_DTYPE: return "tfa: unsupported dtype (q/k/v must be fp16 or bf16; out must match or be fp32)";
-    case TFA_ERR_HEAD_DIM: return "tfa: unsupported head dim (forward: multiples of 8 up to 128; split-KV, merge and backward: 64, 128)";
+    case TFA_ERR_HEAD_DIM: return "tfa: unsupported head dim (forward: multiples of 8 up to 256; split-KV, merge and backward: 64, 128)";
     case TFA_ERR_SHAPE: return "tfa: bad shape (sizes must be positive and H % Hk == 0)";
     case TFA_ERR_STRIDE: return "tfa: bad stride (must be >=0, rows 16-byte aligned and non-overlapping, slice < 2 GiB)";
     case TFA_ERR_ALIGN: return "tfa: base pointers must be 16-byte aligned";

@@ -125,7 +125,7 @@ static __device__ __forceinline__ float pair_sum(float x) {
 // lanes of a ds_read_b128 service group (16 different keys, same chunk) hit 16 different
 // 16-byte slots of the 256-byte bank row.
 template <int D> static __device__ __forceinline__ int k_swz(int row) {
-  return D == 128 ? (row & 15) : ((row >> 1) & 7);
+  return D >= 128 ? (row & 15) : ((row >> 1) & 7);   // (D = 256: 32 chunks per row, the XOR stays inside a 16-chunk half)
 }
 template <int D> static __device__ __forceinline__ int k_lds_off(int row, int chunk) {
   return row * (D * 2) + ((chunk ^ k_swz<D>(row)) << 4);

@@ -119,11 +119,14 @@ constexpr int X4AB_NOEXP = 1, X4AB_NODMA = 2, X4AB_NOBARRIER = 4, X4AB_NOMAX = 8
 #define TFA_X4_DMASTEP 1
 #endif
 
-template <typename T, int D, bool CAUSAL, bool F32OUT, int VF, int AB = 0>
+// RB = 32-row blocks per wave: 2 at D <= 128 (256-row workgroups), 1 at D = 256 (128-row workgroups) — RB * D = 256 keeps O
+// (RB * D/32 * 16 = 128 registers) and Q (RB * D/16 * 4 = 64) in the same hand-owned AGPRs and a tile at 64 MFMAs per wave.
+template <typename T, int D, bool CAUSAL, bool F32OUT, int VF, int AB = 0, int RB = (D <= 128 ? 2 : 1)>
 __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   using M = X4<T>;
   using X8 = typename M::X8;
-  constexpr int NW = 4, RB = 2;
+  constexpr int NW = 4;
+  static_assert(RB * D <= 256 && (RB == 1 || RB == 2), "O and Q must fit a0..a191");
   constexpr int BM = NW * RB * 32;                 // 256 query rows per workgroup
   constexpr int BN = 64;
   constexpr int CPR = D / 8;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   constexpr int N1 = RB * NKF;                     // S MFMAs per tile
   constexpr int N2 = RB * NVF;                     // PV MFMAs per tile
   constexpr int NE = RB * 32;                      // softmax elements per lane per tile
-  constexpr int NE1 = TFA_X4_NE1;                  // of those, summed/packed during part 1
+  constexpr int NE1 = TFA_X4_NE1 * RB / 2;         // of those, summed/packed during part 1
   constexpr int PF = TFA_X4_PF;                    // fragment read-ahead, in fragments (= 2 MFMAs each)
   constexpr int NKB = 3;                           // K ring
   constexpr bool PAIR = CAUSAL && (VF & VF_PAIR);
@@ -149,8 +152,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   // e = 8 * pp + n % 8 is its index among the row block's 32 elements.  The order is the order of need: PV MFMA
   // N1 + RB*DT*pp is the first to read P slot pp.  MFMA slot (0..N1+N2-1) in which element n is summed and packed:
 #define X4_SLOT_OF(n) x4_slot_of<N1, NE1, NE, RB * DT * 3 - 1>(n)
-  static_assert(X4_SLOT_OF(15) < N1 && X4_SLOT_OF(31) < N1 + RB * DT && X4_SLOT_OF(47) < N1 + 2 * RB * DT && X4_SLOT_OF(63) < N1 + 3 * RB * DT,
+  constexpr int EG = 8 * RB;                       // elements per P slot (all row blocks)
+  static_assert(X4_SLOT_OF(EG - 1) < N1 && X4_SLOT_OF(2 * EG - 1) < N1 + RB * DT && X4_SLOT_OF(3 * EG - 1) < N1 + 2 * RB * DT &&
+                    X4_SLOT_OF(4 * EG - 1) < N1 + 3 * RB * DT,
                 "a P slot is packed too late for the PV MFMA that reads it");
+  // element n -> row block and index among the row block's 32 elements
+#define X4_EL_RB(n) (((n) % EG) >> 3)
+#define X4_EL_E(n) (((n) / EG) * 8 + ((n) & 7))
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* const vl = smem + NKB * TILE_BYTES;        // V buffers 0,1 behind the three K buffers
@@ -333,7 +341,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       if (CAUSAL) nm = nm || (key0 + BN - 1 > wave_row0 + shift);
       return nm;
     };
-    auto trigger = [&](const float (&m)[RB]) -> bool { return __any(m[0] * sc > mref[0] + 8.f || m[1] * sc > mref[1] + 8.f); };
+    auto trigger = [&](const float (&m)[RB]) -> bool {
+      bool t = m[0] * sc > mref[0] + 8.f;
+      if constexpr (RB == 2) t = t || (m[1] * sc > mref[1] + 8.f);
+      return __any(t);
+    };
     // cold: row block rb takes its current running max as the new reference; O and l are multiplied by exp2(old - new)
     auto rescale_if_needed = [&](auto rb_c, float mloc) {
       constexpr int rb = decltype(rb_c)::value;
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     // fma -> exp -> add inside one slot would stall on every result).  The empty asm statements pin each result inside the
     // slot it was written in (IR passes otherwise re-associate the row sum into packed adds, tfa_fwd_kernel_il.h).
     auto st_fma = [&](auto n_c, const f32x16 (&s)[RB][2], float (&xs)[NE]) {
-      constexpr int n = decltype(n_c)::value, rb = (n & 15) >> 3, e = (n >> 4) * 8 + (n & 7), slot = e >> 3, t = slot >> 1, r = (slot & 1) * 8 + (e & 7);
+      constexpr int n = decltype(n_c)::value, rb = X4_EL_RB(n), e = X4_EL_E(n), slot = e >> 3, t = slot >> 1, r = (slot & 1) * 8 + (e & 7);
       xs[n] = fmaf(s[rb][t][r], sc, -mref[rb]);
       asm volatile("" : "+v"(xs[n]));
     };
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       asm volatile("" : "+v"(xs[n]));
     };
     auto st_sum = [&](auto n_c, float (&xs)[NE], unsigned (&pw)[RB][16]) {
-      constexpr int n = decltype(n_c)::value, rb = (n & 15) >> 3, e = (n >> 4) * 8 + (n & 7);
+      constexpr int n = decltype(n_c)::value, rb = X4_EL_RB(n), e = X4_EL_E(n);
       l4[rb][e & 3] += xs[n];
       asm volatile("" : "+v"(l4[rb][e & 3]));
       if constexpr (e & 1) {
@@ -383,7 +395,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     };
 
     f32x16 sA[RB][2], sB[RB][2];
-    float mA[RB] = {-INFINITY, -INFINITY}, mB[RB] = {-INFINITY, -INFINITY};
+    float mA[RB], mB[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) mA[rb] = mB[rb] = -INFINITY;
     X8 kpre[PF];                                     // first fragments of the next iteration's K tile, read before the barrier
     // S(t) = K(t) Q^T from the K buffer at kboff, masked, row max per row block (this half-wave's 32 keys only)
     auto qk_burst = [&](unsigned kboff, int t, f32x16 (&s)[RB][2], float (&mout)[RB]) {
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         constexpr int g = decltype(g_c)::value;
         if constexpr ((AB & X4AB_NOEXP) != 0) {
           static_for<0, NE>([&](auto n_c) {
-            constexpr int n = decltype(n_c)::value, rb = (n & 15) >> 3, e = (n >> 4) * 8 + (n & 7);
+            constexpr int n = decltype(n_c)::value, rb = X4_EL_RB(n), e = X4_EL_E(n);
             if constexpr (X4_SLOT_OF(n) == g && (e & 1)) {
               pw[rb][e >> 1] = __builtin_bit_cast(unsigned, scur[rb][e >> 4][e & 15]);
               asm volatile("" : "+v"(pw[rb][e >> 1]));
@@ -499,7 +513,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       // part 1: S(j+1) = K(j+1) Q^T — fragment i feeds the MFMAs 2i (row block 0) and 2i+1 (row block 1)
       static_for<0, N1>([&](auto g_c) {
-        constexpr int g = decltype(g_c)::value, i = g >> 1, rb = g & 1;
+        constexpr int g = decltype(g_c)::value, i = g / RB, rb = g % RB;
         if constexpr (rb == 0) {                       // read-ahead: K fragments, then the first V fragments of part 2
           if constexpr (i + PF < NKF) kf[i + PF] = (AB & X4AB_NOKREAD) ? kf[i % PF] : k_frag(kb1, i + PF);
           else vf[i + PF - NKF] = v_frag(vbp, i + PF - NKF);
@@ -515,11 +529,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         soft_slot(g_c);
         __builtin_amdgcn_sched_barrier(0);
       });
-      // part 2: O += P(j) V(j) — fragment i feeds the MFMAs 2i and 2i+1; row max of S(j+1): chain c = (kt, rb) finished
-      // at MFMA N1 - 4 + c of part 1 and is read from MFMA (N2/4) * c of part 2 on
-      float mx[RB] = {-INFINITY, -INFINITY};
+      // part 2: O += P(j) V(j) — fragment i feeds the MFMAs RB*i .. RB*i + RB-1; row max of S(j+1): chain c = kt * RB + rb
+      // finished at MFMA N1 - 2*RB + c of part 1 and is read from MFMA (N2 / (2*RB)) * c of part 2 on
+      float mx[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) mx[rb] = -INFINITY;
       static_for<0, N2>([&](auto g_c) {
-        constexpr int g = decltype(g_c)::value, i = g >> 1, rb = g & 1;
+        constexpr int g = decltype(g_c)::value, i = g / RB, rb = g % RB;
         if constexpr (rb == 0) {
           if constexpr (i + PF < NVF) vf[i + PF] = (AB & X4AB_NOVREAD) ? vf[i % PF] : v_frag(vbp, i + PF);
 #if defined(TFA_X4_BRANCHY_KPRE)
@@ -533,10 +549,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         dma_slot(std::integral_constant<int, N1 + g>{});
         soft_slot(std::integral_constant<int, N1 + g>{});
         if constexpr (!(AB & X4AB_NOMAX)) {
-          static_for<0, 32>([&](auto q_c) {            // 32 pairs of S(j+1) values -> one v_max3 each
+          static_for<0, 16 * RB>([&](auto q_c) {       // 16 pairs of S(j+1) values per row block -> one v_max3 each
             constexpr int q = decltype(q_c)::value;
-            if constexpr (q * N2 / 32 == g) {
-              constexpr int c = q >> 3, kt = c >> 1, r2 = c & 1;
+            if constexpr (q * N2 / (16 * RB) == g) {
+              constexpr int c = q >> 3, kt = c / RB, r2 = c % RB;
               mx[r2] = fmaxf(fmaxf(mx[r2], snext[r2][kt][2 * (q & 7)]), snext[r2][kt][2 * (q & 7) + 1]);
               asm volatile("" : "+v"(mx[r2]));
             }
@@ -576,11 +592,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       static_for<0, NVF>([&](auto i_c) {
         constexpr int i = decltype(i_c)::value;
         const X8 vfr = v_frag(vbp, i);
-        X8 p0 = p_frag(pw, 0, i / DT), p1 = p_frag(pw, 1, i / DT);
+        X8 p0 = p_frag(pw, 0, i / DT), p1 = p_frag(pw, RB - 1, i / DT);
         asm volatile("s_nop 1" : "+v"(p0), "+v"(p1));    // VALU write -> MFMA operand: 2 wait states
         if (dbg & 4) big_fence();
         M::template pv<(0 * DT + i % DT) * 16>(vfr, p0);
-        M::template pv<(1 * DT + i % DT) * 16>(vfr, p1);
+        if constexpr (RB == 2) M::template pv<(1 * DT + i % DT) * 16>(vfr, p1);
       });
       if (j + 1 < nact) qk_burst(kb1, j + 1, snext, mnext);
       if (!(dbg & 32) && j + 2 < nact) load_kpre(kb2);
@@ -691,5 +707,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
 }
 
 #undef X4_SLOT_OF
+#undef X4_EL_RB
+#undef X4_EL_E
 
 }  // namespace tfa
