@@ -24,14 +24,20 @@ def regs(tok):
 
 bad = 0
 for f in files:
-    ins = []
+    ins, asm_lines, inasm = [], set(), False
     for ln, line in enumerate(open(f), 1):
+        if "#ASMSTART" in line:
+            inasm = True
+        if "#ASMEND" in line:
+            inasm = False
         t = line.split(";")[0].strip()
         if not t or t.startswith(".") or t.endswith(":"):
             continue
         ins.append((ln, t))
+        if inasm:
+            asm_lines.add(ln)      # only inline-asm MFMAs are audited: hipcc pads the hazards of the builtin ones itself
     for idx, (ln, t) in enumerate(ins):
-        if not t.startswith("v_mfma"):
+        if not t.startswith("v_mfma") or ln not in asm_lines:
             continue
         ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
         src = set()
@@ -57,7 +63,7 @@ for f in files:
     #     the XDL-write -> VALU hazard of a 16-pass MFMA is 19 wait states
     NEED_RES = 19
     for idx, (ln, t) in enumerate(ins):
-        if not t.startswith("v_mfma"):
+        if not t.startswith("v_mfma") or ln not in asm_lines:
             continue
         ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
         dst = regs(ops[0])
