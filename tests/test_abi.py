@@ -316,3 +316,53 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert r.returncode == 0, r.stderr[:2000]
     run = subprocess.run([str(exe)], capture_output=True, text=True)
     assert run.returncode == 0, (run.returncode, run.stderr[:500])
+
+
+def test_assembly_audit_tools_flag_what_they_exist_for(tmp_path):
+    """The x4 and il units are built through two audits of hipcc's generated assembly (csrc/Makefile).  Feed them the two
+    defects they were written for: an AGPR restore of an MFMA operand directly in front of an inline-asm MFMA (the x4
+    kernel's row-block-0 bug of round 2) and a compiler-parked value in a hand-owned AGPR."""
+    import subprocess
+    import sys
+
+    bad = tmp_path / "bad.s"
+    bad.write_text(
+        "kern:\n"
+        "\tv_accvgpr_write_b32 a130, v7\n"                     # compiler parks a value in an owned register (outside asm)
+        "\tds_read_b128 v[10:13], v1\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tv_accvgpr_read_b32 v13, a229\n"                     # VALU write of an MFMA operand ...
+        "\t;;#ASMSTART\n"
+        "\tv_mfma_f32_32x32x16_bf16 v[18:33], v[10:13], a[128:131], 0\n"   # ... zero wait states before the asm MFMA
+        "\t;;#ASMEND\n"
+        "\tv_add_f32_e32 v90, v18, v19\n"                      # and its result read before the passes are over
+        "\ts_endpgm\n")
+    good = tmp_path / "good.s"
+    good.write_text(
+        "kern:\n"
+        "\tv_accvgpr_write_b32 a200, v7\n"
+        "\tv_accvgpr_read_b32 v13, a229\n"
+        "\ts_nop 1\n"
+        "\t;;#ASMSTART\n"
+        "\tv_mfma_f32_32x32x16_bf16 v[18:33], v[10:13], a[128:131], 0\n"
+        "\t;;#ASMEND\n"
+        "\t;;#ASMSTART\n"
+        "\tv_mfma_f32_32x32x16_bf16 v[34:49], v[10:13], a[132:135], 0\n"
+        "\t;;#ASMEND\n"
+        "\t;;#ASMSTART\n"
+        "\tv_mfma_f32_32x32x16_bf16 v[50:65], v[10:13], a[136:139], 0\n"
+        "\t;;#ASMEND\n"
+        "\t;;#ASMSTART\n"
+        "\tv_mfma_f32_32x32x16_bf16 v[66:81], v[10:13], a[140:143], 0\n"
+        "\t;;#ASMEND\n"
+        "\tv_add_f32_e32 v90, v18, v19\n"                      # three MFMAs later: the result has left the pipe
+        "\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n"
+        "\ts_endpgm\n")
+    hz = os.path.join(ROOT, "tools", "audit_mfma_hazard.py")
+    ag = os.path.join(ROOT, "tools", "audit_agpr.sh")
+    r = subprocess.run([sys.executable, hz, str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "MFMA hazards: 2" in r.stdout, r.stdout
+    r = subprocess.run([sys.executable, hz, str(good)], capture_output=True, text=True)
+    assert r.returncode == 0 and "MFMA hazards: 0" in r.stdout, r.stdout
+    assert len(subprocess.run(["bash", ag, str(bad)], capture_output=True, text=True).stdout.strip().splitlines()) == 1
+    assert subprocess.run(["bash", ag, str(good)], capture_output=True, text=True).stdout.strip() == ""
