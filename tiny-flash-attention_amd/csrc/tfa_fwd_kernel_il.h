@@ -275,7 +275,10 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     const int qoff = (q0x + wave * 32 + qi) * (int)p.qs_n * 2 + hi * 16;
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
-      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, (2 * s + hi) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB, 0, 0);
+#ifndef TFA_IL_QLOAD_AUX
+#define TFA_IL_QLOAD_AUX 0
+#endif
+      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, (2 * s + hi) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB, 0, TFA_IL_QLOAD_AUX);
       qf[s] = __builtin_bit_cast(X8, t);
     }
   };
@@ -680,7 +683,11 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         const int r = i * RPI + lanex / CH, cpos = lanex % CH;
         const int c = cpos ^ ((CH == 16) ? (r & 15) : (r & 7));
         u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
-        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, 0);
+#ifndef TFA_IL_OSTORE_AUX
+#define TFA_IL_OSTORE_AUX 2     // cache policy of the O row stores: nt — O is written once and never re-read, the XCD's L2 is better spent on
+                                // the K/V tiles every query block of the head re-reads (cfg3: +1.8 %, others +-0; profiles/r02_ostore_ab.txt)
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, TFA_IL_OSTORE_AUX);
       }
       if (INPLACE) {
         // the next pass's first DMA pieces land in these buffers: every wave must have read its rows back
