@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
-    // ---- fast path: tile j (S in scur) -> O; S(j+1) and its row max -> snext, mnext.  Unmasked tiles only. -------
+    // ---- fast path: tile j (S in scur) -> O; S(j+1) and its row max -> snext, mnext. ------------------------------
     // PAR = j & 1: V(j) is in V buffer PAR, V(j+1) -> V buffer PAR^1; K(j+1) at kb1 (first PF fragments already in
     // kpre), K(j+2) at kb2 (its first fragments are read in the tail), K(j+3) -> kb0.
     auto fused = [&](auto par_c, int j, f32x16 (&scur)[RB][2], f32x16 (&snext)[RB][2], float (&mnext)[RB]) {
@@ -529,6 +529,17 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         soft_slot(g_c);
         __builtin_amdgcn_sched_barrier(0);
       });
+      // tile j+1 is the wave's masked (diagonal / ragged) tile: S(j+1) is complete, mask it here, in a wave-uniform branch of
+      // the fast path (the fence covers the MFMA -> VALU distance) instead of sending tile j through the burst path
+      if (j + 1 >= fm) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          x4_fence_v(snext[rb][0]);
+          x4_fence_v(snext[rb][1]);
+          apply_mask(j + 1, rb, snext[rb]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // part 2: O += P(j) V(j) — fragment i feeds the MFMAs RB*i .. RB*i + RB-1; row max of S(j+1): chain c = kt * RB + rb
       // finished at MFMA N1 - 2*RB + c of part 1 and is read from MFMA (N2 / (2*RB)) * c of part 2 on
       float mx[RB];
@@ -604,18 +615,18 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     };
 
     // S(j) lives in sA for even j and in sB for odd j on both paths, so the paths alternate freely without copies.
-    // Tile j takes the fast path when tile j+1 exists for this wave, needs no mask, and no row max of tile j has
-    // outgrown its reference; everything else (at most the wave's last two tiles, and re-bases) takes the slow path.
+    // Tile j takes the fast path when tile j+1 exists for this wave and no row max of tile j has outgrown its reference;
+    // the wave's last tile and re-bases take the slow path.
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
 #pragma nounroll
     for (int j = 0; j < nact; j += 2) {
-      if (!(dbg & 1) && j + 1 < fm && j + 1 < nact && !trigger(mA)) fused(C0{}, j, sA, sB, mB);
-      else { if (p.trace && j + 1 < fm && j + 1 < nact) ++n_trig; slow(j, sA, mA, sB, mB); }
+      if (!(dbg & 1) && j + 1 < nact && !trigger(mA)) fused(C0{}, j, sA, sB, mB);
+      else { if (p.trace && j + 1 < nact) ++n_trig; slow(j, sA, mA, sB, mB); }
       rotate();
       if (j + 1 >= nact) break;
-      if (!(dbg & 1) && j + 2 < fm && j + 2 < nact && !trigger(mB)) fused(C1{}, j + 1, sB, sA, mA);
-      else { if (p.trace && j + 2 < fm && j + 2 < nact) ++n_trig; slow(j + 1, sB, mB, sA, mA); }
+      if (!(dbg & 1) && j + 2 < nact && !trigger(mB)) fused(C1{}, j + 1, sB, sA, mA);
+      else { if (p.trace && j + 2 < nact) ++n_trig; slow(j + 1, sB, mB, sA, mA); }
       rotate();
     }
 #pragma nounroll
@@ -673,7 +684,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
           const int r = i * RPI + lanex / CH, cpos = lanex % CH;
           const int c = cpos ^ ((CH == 16) ? (r & 15) : (r & 7));
           u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
-          __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 + rb * 32 + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 + rb * 32 + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, 2);   // nt: see tfa_fwd_kernel_il.h
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by this wave's next epilogue only
       } else {
