@@ -117,6 +117,26 @@ def test_rejects_bad_descriptors():
     assert _lib.strerror(0) == "success"
 
 
+def test_slices_beyond_2_gib_are_windowed_not_refused():
+    # (B,N,H,D) storage, H*D*2 = 128 KiB per row: a head slice of 20000 rows spans 2.6 GB.  The default il kernel takes it
+    # (its windowed instantiation); the split-KV kernel (variant 17) and head dims > 128 (one descriptor per slice) must refuse.
+    p = _params(B=1, H=512, Hk=512, Nq=20000, Nk=20000, D=128)
+    for name in ("q_stride", "k_stride", "v_stride", "o_stride"):
+        a = getattr(p, name)
+        a[0], a[1], a[2] = 20000 * 512 * 128, 128, 512 * 128
+    assert plan(p)[0] == 0
+    _lib.set_variant(17)
+    try:
+        assert plan(p)[0] == -5
+    finally:
+        _lib.set_variant(-1)
+    p.D = 256
+    assert plan(p)[0] == -5
+    p.D = 128
+    a = p.k_stride; a[2] = 8 * 1024 * 1024                  # 16 MiB per row: even one 64-row tile window exceeds 2 GiB
+    assert plan(p)[0] == -5
+
+
 def test_f32_out_and_gqa_accepted():
     assert plan(_params(out_dtype=_lib.TFA_F32))[0] == 0   # fp32 debug output
     assert plan(_params(H=8, Hk=2))[0] == 0

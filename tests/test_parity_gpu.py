@@ -516,6 +516,67 @@ def test_strided_bnhd_matches_bhnd(tfa, oracle, dev, variant):
     assert torch.equal(o_bnhd.transpose(1, 2), o_bhnd) and torch.equal(l_bnhd, l_bhnd)
 
 
+def test_head_slices_beyond_2_gib_in_bnhd_layout(tfa, dev):
+    """(B,N,H,D) storage with many heads: one (b,h) slice spans N * H*D*2 bytes — here 2.2 GiB, more than a 32-bit buffer
+    offset reaches.  The default il kernel then runs in its windowed instantiation (per-query-block and per-tile
+    descriptors, rsrc_at in tfa_fwd_kernel.h); checked on sampled heads against a device fp32 reference (the rows near the
+    END of the sequence are the ones whose offsets exceed 2 GiB).  The single-descriptor kernels (split-KV, backward, head
+    dims > 128) still refuse."""
+    from tiny_flash_attention_amd import _lib, ops
+
+    B, N, H, D = 1, 17408, 512, 128                       # row stride H*D*2 = 128 KiB -> slice = 2.28e9 bytes
+    assert (N - 1) * H * D * 2 > 2 ** 31
+    g = torch.Generator(device=dev).manual_seed(91)
+    mk = lambda: torch.empty((B, N, H, D), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(torch.bfloat16)
+    q, k, v = mk(), mk(), mk()
+    sc = 1.0 / math.sqrt(D)
+    out, lse = ops.flash_attn_fwd(q, k, v, True, sc, layout="bnhd")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out[:, -512:].float()).all())
+    for h in (0, 257, 511):
+        qh, kh, vh = (t[0, :, h].float() for t in (q, k, v))            # (N, D)
+        rows = slice(N - 640, N)                                          # the tail of the sequence, all keys
+        s_ = (qh[rows] @ kh.t()) * sc
+        idx = torch.arange(N, device=dev)
+        s_.masked_fill_(idx[None, :] > idx[rows, None], float("-inf"))
+        ref = torch.softmax(s_, dim=-1) @ vh
+        assert (out[0, rows, h].float() - ref).abs().max().item() <= 1e-2
+        assert (lse[0, h, rows] - torch.logsumexp(s_, dim=-1)).abs().max().item() <= 1e-4
+        s0 = (qh[:256] @ kh[:256].t()) * sc                              # and the head of the sequence
+        s0.masked_fill_(idx[None, :256] > idx[:256, None], float("-inf"))
+        assert (out[0, :256, h].float() - torch.softmax(s0, dim=-1) @ vh[:256]).abs().max().item() <= 1e-2
+    with pytest.raises(_lib.TfaError):                                    # split-KV runs the single-descriptor kernel
+        ops.flash_attn_fwd_splitkv(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), True, sc, splits=2)
+
+
+@pytest.mark.parametrize("variant", [30, 32])
+@pytest.mark.parametrize("causal", [False, True])
+def test_windowed_instantiation_returns_the_same_bits(tfa, dev, variant, causal):
+    """The windowed instantiation (launched for slices >= 2 GiB) forced onto ordinary inputs through the debug flag:
+    bit-identical output and LSE, ragged lengths, Nq != Nk, GQA, strided (B,N,H,D) storage and a padded head dim included."""
+    from tiny_flash_attention_amd import _lib, ops
+
+    g = torch.Generator(device=dev).manual_seed(92)
+    cases = [(2, 4, 4, 1024, 1024, 128, "bhnd"), (1, 4, 2, 777, 1333, 128, "bnhd"), (2, 2, 2, 1500, 1500, 64, "bnhd"),
+             (1, 2, 2, 640, 640, 96, "bhnd")]
+    _lib.set_variant(variant)
+    try:
+        for B, H, Hk, Nq, Nk, D, layout in cases:
+            shp = (lambda n, h: (B, h, n, D)) if layout == "bhnd" else (lambda n, h: (B, n, h, D))
+            mk = lambda n, h: torch.empty(shp(n, h), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(torch.bfloat16)
+            q, k, v = mk(Nq, H), mk(Nk, Hk), mk(Nk, Hk)
+            sc = 1.0 / math.sqrt(D)
+            o0, l0 = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout)
+            _lib.debug_set_flags(256)
+            try:
+                o1, l1 = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout)
+            finally:
+                _lib.debug_set_flags(0)
+            assert torch.equal(o0, o1) and torch.equal(l0, l1), (B, H, Hk, Nq, Nk, D, layout)
+    finally:
+        _lib.set_variant(-1)
+
+
 def test_dropin_extension_module_attention_cutlass(tfa, oracle, dev):
     """`from attention_cutlass import flash_attention_v2_cutlass` — the reference's own import line
     (flash_attention_cutlass/test.py:3) — resolves to the C++ binding over the C ABI and returns the

@@ -182,6 +182,11 @@ def set_variant(v):
     check(lib().tfa_set_variant(int(v)))
 
 
+def debug_set_flags(flags):
+    """Bring-up flags of the calling thread (include/tfa.h: tfa_debug_set_flags); 0 = normal."""
+    check(lib().tfa_debug_set_flags(int(flags)))
+
+
 def get_variant():
     return lib().tfa_get_variant()
 

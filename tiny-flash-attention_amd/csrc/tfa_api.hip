@@ -50,13 +50,20 @@ int pick_variant(const tfa_fwd_params* p) {
   return tfa::kDefaultVariant;
 }
 
-// extent in bytes of one (b,h) slice: rows 0..N-1 at row stride, D contiguous elements each
-bool slice_bytes(int64_t n, int64_t row_stride, int d, int esize, unsigned* out) {
+// extent in bytes of one (b,h) slice: rows 0..N-1 at row stride, D contiguous elements each.  Kernels with one descriptor
+// per slice need every byte offset they form (up to one block past the end) inside int32; the il / x4 kernels address the
+// slice through per-block / per-tile windows (rsrc_at), so only a WINDOW (a 256-row query block or a 64-row tile plus the
+// rows a ragged tail may reach past it) has to fit 2 GiB — long (B,N,H,D) tensors whose head slices span more are fine.
+bool slice_bytes(int64_t n, int64_t row_stride, int d, int esize, bool windowed, unsigned long long* out, int* big) {
   const int64_t bytes = ((n - 1) * row_stride + d) * esize;
-  // keep every byte offset the kernel forms (up to one block past the end) inside int32
-  const int64_t reach = ((n + 512) * row_stride + d) * esize;
-  if (bytes <= 0 || reach >= (int64_t)0x7fffffff) return false;
-  *out = (unsigned)bytes;
+  const int64_t whole = ((n + 512) * row_stride + d) * esize;       // one descriptor per slice
+  const int64_t window = (768 * row_stride + d) * esize;            // one per query block / tile
+  if (bytes <= 0) return false;
+  if (whole >= (int64_t)0x7fffffff) {
+    if (!windowed || window >= (int64_t)0x7fffffff) return false;
+    *big = 1;
+  }
+  *out = (unsigned long long)bytes;
   return true;
 }
 
@@ -99,10 +106,12 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   a->ks_b = p->k_stride[0]; a->ks_h = p->k_stride[1]; a->ks_n = p->k_stride[2];
   a->vs_b = p->v_stride[0]; a->vs_h = p->v_stride[1]; a->vs_n = p->v_stride[2];
   a->os_b = p->o_stride[0]; a->os_h = p->o_stride[1]; a->os_n = p->o_stride[2];
-  if (!slice_bytes(p->Nq, a->qs_n, p->D, esz, &a->q_bytes)) return TFA_ERR_STRIDE;
-  if (!slice_bytes(p->Nk, a->ks_n, p->D, esz, &a->k_bytes)) return TFA_ERR_STRIDE;
-  if (!slice_bytes(p->Nk, a->vs_n, p->D, esz, &a->v_bytes)) return TFA_ERR_STRIDE;
-  if (!slice_bytes(p->Nq, a->os_n, p->D, osz, &a->o_bytes)) return TFA_ERR_STRIDE;
+  const bool win = !ablate && tfa::windowed_slices(variant);
+  if (!slice_bytes(p->Nq, a->qs_n, p->D, esz, win, &a->q_bytes, &a->big)) return TFA_ERR_STRIDE;
+  if (!slice_bytes(p->Nk, a->ks_n, p->D, esz, win, &a->k_bytes, &a->big)) return TFA_ERR_STRIDE;
+  if (!slice_bytes(p->Nk, a->vs_n, p->D, esz, win, &a->v_bytes, &a->big)) return TFA_ERR_STRIDE;
+  if (!slice_bytes(p->Nq, a->os_n, p->D, osz, win, &a->o_bytes, &a->big)) return TFA_ERR_STRIDE;
+  if ((g_dbg_flags & 256) && win) a->big = 1;   // tests: run the windowed instantiation on a small problem
   a->scale = p->softmax_scale;
   a->trace = g_trace;
   a->grid = num_cus();
@@ -165,7 +174,7 @@ const char* tfa_strerror(int status) {
     case TFA_ERR_DTYPE: return "tfa: unsupported dtype (q/k/v must be fp16 or bf16; out must match or be fp32)";
     case TFA_ERR_HEAD_DIM: return "tfa: unsupported head dim (forward: multiples of 8 up to 256; split-KV, merge and backward: 64, 128)";
     case TFA_ERR_SHAPE: return "tfa: bad shape (sizes must be positive and H % Hk == 0)";
-    case TFA_ERR_STRIDE: return "tfa: bad stride (must be >=0, rows 16-byte aligned and non-overlapping, slice < 2 GiB)";
+    case TFA_ERR_STRIDE: return "tfa: bad stride (must be >=0, rows 16-byte aligned and non-overlapping; 768 rows of a (b,h) slice must span < 2 GiB, the whole slice for split-KV / backward)";
     case TFA_ERR_ALIGN: return "tfa: base pointers must be 16-byte aligned";
     case TFA_ERR_VARIANT: return "tfa: unknown kernel variant";
     case TFA_ERR_SCALE: return "tfa: softmax_scale must be finite and > 0";

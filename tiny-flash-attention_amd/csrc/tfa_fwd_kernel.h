@@ -55,7 +55,10 @@ struct KArgs {
   long long ks_b, ks_h, ks_n;
   long long vs_b, vs_h, vs_n;
   long long os_b, os_h, os_n;
-  unsigned q_bytes, k_bytes, v_bytes, o_bytes;   // extent of one (b,h) slice, for the buffer descriptors
+  unsigned long long q_bytes, k_bytes, v_bytes, o_bytes;   // extent of one (b,h) slice in bytes.  Kernels use ONE descriptor per slice
+                    // (< 2 GiB); the il kernels also exist in a WINDOWED instantiation (VF_IL_WINDOWED: rsrc_at, one query
+                    // block / one K/V tile per descriptor) that tfa_api.hip launches when a slice is larger
+  int big;          // some slice does not fit one descriptor: launch the windowed instantiation
   float scale;      // softmax_scale
   float scale_log2; // softmax_scale * log2(e)
   int grid;         // workgroups launched (persistent kernels walk work items with this stride)
@@ -144,6 +147,18 @@ template <int D> static __device__ __forceinline__ int v_lds_off(int key, int ch
 // Used with UNSIGNED arithmetic: OOB + any tile offset (< 2^31) stays >= 2^31 without wrapping.
 constexpr unsigned TFA_OOB = 0x80000000u;
 
+// Buffer descriptor over [base + off, base + total): the window a kernel addresses with 32-bit offsets.  At most 2 GiB - 1 bytes
+// are visible through it; what lies beyond `total` reads as zeros / drops stores exactly as with a whole-slice descriptor.
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_at(const void* base, unsigned long long total, unsigned long long off) {
+  // 32-bit scalar pieces only (a 64-bit compare goes through the VALU): rem = total - off as a signed 64-bit value
+  const unsigned long long rem = total - off;
+  const unsigned hi = (unsigned)(rem >> 32), lo = (unsigned)rem;
+  unsigned n = lo < 0x7fffffffu ? lo : 0x7fffffffu;
+  n = hi ? 0x7fffffffu : n;
+  n = ((int)hi < 0) ? 0u : n;                        // off beyond the slice: nothing visible
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(base) + off), 0, n, 0x00020000);
+}
+
 // Variant flags
 constexpr int VF_TRREAD = 1;     // V fragments by ds_read_b64_tr_b16 (else 16-bit gathers)
 constexpr int VF_NOSKIP = 2;     // always rescale O (no exact alpha==1 skip)
@@ -214,9 +229,9 @@ __global__ __launch_bounds__(NW * 64, RB == 1 ? 2 : 1) void fwd_kernel(const KAr
   const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
   const T* kbase = reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h;
   const T* vbase = reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h;
-  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, p.q_bytes, 0x00020000);
-  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
-  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
+  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, (unsigned)p.q_bytes, 0x00020000);
+  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (unsigned)p.k_bytes, 0x00020000);
+  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (unsigned)p.v_bytes, 0x00020000);
 
   // ---- staging geometry (constant per thread) ----------------------------------------------
   int st_koff[NCH], st_voff[NCH];            // byte offset inside the (b,h) slice for tile 0
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(NW * 64, RB == 1 ? 2 : 1) void fwd_kernel(const KAr
       // lane holds, for its row, d = 32*dt + 8*g + 4*hi + {0..3}  (g = r>>2)
       if (F32OUT) {
         float* obase = reinterpret_cast<float*>(p.o) + b * p.os_b + h * p.os_h;
-        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
         const int ooff = my_row[rb] * (int)p.os_n * 4 + hi * 16;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
@@ -506,7 +521,7 @@ __global__ __launch_bounds__(NW * 64, RB == 1 ? 2 : 1) void fwd_kernel(const KAr
           }
       } else {
         T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
-        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
         const int ooff = my_row[rb] * (int)p.os_n * 2 + hi * 8;
         typedef __attribute__((ext_vector_type(4))) T t4;
 #pragma unroll

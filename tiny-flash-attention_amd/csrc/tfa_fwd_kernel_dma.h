@@ -49,6 +49,18 @@ static __device__ __forceinline__ void lds_dma16_m0(__amdgpu_buffer_rsrc_t rs, u
       : "memory", "m0");
 }
 
+// LDS-DMA through a descriptor computed just before (per-tile windows): a VMEM instruction reading an SGPR that SALU code
+// wrote needs 5 wait states, and nothing pads the inside of an asm.
+static __device__ __forceinline__ void lds_dma16_m0_fresh(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, int voffset) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %1, %2, 0 offen lds"
+      :
+      : "s"(lds_addr), "v"(voffset), "s"(rs)
+      : "memory", "m0");
+}
+
 constexpr int VF_PERSIST = 2048;   // launch one workgroup per CU and walk the work items (else one item per workgroup)
 constexpr int VF_2BUF = 4096;      // two LDS tile buffers (64 KiB at D=128): two 4-wave workgroups fit one CU
 constexpr int VF_LDSEPI = 16384;   // epilogue: transpose O through LDS and store whole rows (16-byte coalesced stores)
@@ -157,8 +169,8 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
     }
     k.nt = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
     const int b = k.bh / p.H, h = k.bh - b * p.H, hk = h / (p.H / p.Hk);
-    k.q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h), 0, p.q_bytes, 0x00020000);
-    unsigned kb = p.k_bytes, vb = p.v_bytes;
+    k.q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h), 0, (unsigned)p.q_bytes, 0x00020000);
+    unsigned kb = (unsigned)p.k_bytes, vb = (unsigned)p.v_bytes;
     long long koff = 0, voff = 0;
     if (nsplit > 1) {                                            // descriptor over the chunk only: OOB rows read as zeros
       koff = (long long)k.sp * p.chunk * p.ks_n;
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
     }
     if (F32OUT) {
       float* obase = reinterpret_cast<float*>(p.o) + o_part + ob * p.os_b + oh * p.os_h;
-      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
       const int ooff = my_row * (int)p.os_n * 4 + hi * 16;
 #pragma unroll
       for (int d = 0; d < DT; ++d)
@@ -406,7 +418,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
       // 32 x D tile through its own slice of the (now idle) K buffers — 16-byte chunk index XOR row, as for K —
       // and writes whole rows: 1 KiB contiguous per store instruction.
       T* obase = reinterpret_cast<T*>(p.o) + o_part + ob * p.os_b + oh * p.os_h;
-      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
       typedef __attribute__((ext_vector_type(4))) T t4;
       char* const ow = smem + wave * (32 * D * 2);
       constexpr int CH = D / 8;                      // 16-byte chunks per row
@@ -436,7 +448,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
       }
     } else {
       T* obase = reinterpret_cast<T*>(p.o) + o_part + ob * p.os_b + oh * p.os_h;
-      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
       const int ooff = my_row * (int)p.os_n * 2 + hi * 8;
       typedef __attribute__((ext_vector_type(4))) T t4;
 #pragma unroll

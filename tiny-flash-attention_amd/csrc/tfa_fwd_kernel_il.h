@@ -35,6 +35,8 @@ constexpr int VF_IL_PREF = 524288;       // the next pass's K(0)/V(0)/K(1)/Q are
 constexpr int VF_IL_SEAM = 2097152;      // causal pairs: the heavy pass's last two iterations already request the light pass's K(0), K(1), V(0)
                                          // (same head, same K/V: the tile stream simply continues across the seam) and its Q
                                          // fragments are requested before the epilogue: the second prologue finds everything on chip
+constexpr int VF_IL_WINDOWED = 1 << 24;  // K/V tiles through per-tile descriptors (rsrc_at): a (b,h) slice may exceed 2 GiB.  ~6 % slower (a fresh
+                                         // descriptor per tile: ~14 SALU + the SGPR->VMEM wait states), so only launched when needed
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
                                          // so the two waves of a SIMD never sit in an LDS-DMA issue stall at the same time
 
@@ -175,6 +177,12 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef TFA_IL_WPERM
+#define TFA_IL_WPERM 0
+#endif
+  // the 32-row block of a wave.  Causal, 8 waves: waves w and w+4 share a SIMD and the diagonal block gives row block r
+  // ceil((r+1)/2) tiles — with the identity the SIMDs get 4,4,6,6 tiles, with {0,1,2,3,7,6,5,4} they get 5,4,5,4
+  const int wrow = (TFA_IL_WPERM && CAUSAL && NW == 8 && wave >= 4) ? 11 - wave : wave;
   const int qi = lane & 31;
   const int hi = lane >> 5;
 
@@ -198,9 +206,10 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
   const T* kbase = reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h;
   const T* vbase = reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h;
-  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, p.q_bytes, 0x00020000);
-  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
-  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
+  // Q/O: one descriptor per query block (rsrc_at, once per pass).  K/V: one per slice, or — VF_IL_WINDOWED — one per tile.
+  constexpr bool WIN = (VF & VF_IL_WINDOWED) != 0;
+  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, WIN ? 0u : (unsigned)p.k_bytes, 0x00020000);
+  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, WIN ? 0u : (unsigned)p.v_bytes, 0x00020000);
 
   int k_src[PPW], v_src[PPW];
 #pragma unroll
@@ -224,10 +233,12 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const int v_tile_stride = BN * (int)p.vs_n * 2;
 
   auto dma_k1 = [&](int t, int buf, int i) {
-    lds_dma16_m0(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
+    if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(kbase, p.k_bytes, (unsigned long long)t * (unsigned)k_tile_stride), lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i]);
+    else lds_dma16_m0(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
   };
   auto dma_v1 = [&](int t, int buf, int i) {
-    lds_dma16_m0(v_rs, lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i] + t * v_tile_stride);
+    if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(vbase, p.v_bytes, (unsigned long long)t * (unsigned)v_tile_stride), lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i]);
+    else lds_dma16_m0(v_rs, lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i] + t * v_tile_stride);
   };
   auto dma_k = [&](int t, int buf) {
 #pragma unroll
@@ -272,7 +283,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     if (with_dma && ntx > 0) dma_k(0, 0);
     if (with_dma && ntx > 0) dma_v(0, 0);
     if (with_dma && ntx > 1) dma_k(1, 1);
-    const int qoff = (q0x + wave * 32 + qi) * (int)p.qs_n * 2 + hi * 16;
+    auto q_rs = rsrc_at(qbase, p.q_bytes, WIN ? (unsigned long long)q0x * (unsigned long long)p.qs_n * 2ull : 0ull);
+    const int qoff = ((WIN ? 0 : q0x) + wrow * 32 + qi) * (int)p.qs_n * 2 + hi * 16;
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
 #ifndef TFA_IL_QLOAD_AUX
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     const int nt = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
     nt_total += nt;
 
-    const int wave_row0 = q0 + wave * 32;
+    const int wave_row0 = q0 + wrow * 32;
     const int my_row = wave_row0 + qi;
     const int wave_last_tile = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (nt - 1);
 
@@ -636,8 +648,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     }
     if (F32OUT) {
       float* obase = reinterpret_cast<float*>(p.o) + b * p.os_b + h * p.os_h;
-      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
-      const int ooff = my_row * (int)p.os_n * 4 + hi * 16;
+      auto o_rs = rsrc_at(obase, p.o_bytes, WIN ? (unsigned long long)q0 * (unsigned long long)p.os_n * 4ull : 0ull);
+      const int ooff = (my_row - (WIN ? q0 : 0)) * (int)p.os_n * 4 + hi * 16;
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         float o[16];
@@ -654,7 +666,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       // slice of the epilogue region (16-byte chunk index XOR row, as for K) and writes whole rows: 1 KiB contiguous per
       // store instruction.  The region is separate from the tile buffers (which the next pass is already filling).
       T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
-      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      auto o_rs = rsrc_at(obase, p.o_bytes, WIN ? (unsigned long long)q0 * (unsigned long long)p.os_n * 2ull : 0ull);
       typedef __attribute__((ext_vector_type(4))) T t4;
       // (the lane ids go through an empty asm so that none of the 24 addresses below is loop-invariant: hoisted out of
       // the pass loop they would stay live across the main loop and spill)
@@ -687,7 +699,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #define TFA_IL_OSTORE_AUX 2     // cache policy of the O row stores: nt — O is written once and never re-read, the XCD's L2 is better spent on
                                 // the K/V tiles every query block of the head re-reads (cfg3: +1.8 %, others +-0; profiles/r02_ostore_ab.txt)
 #endif
-        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, TFA_IL_OSTORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 - (WIN ? q0 : 0) + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, TFA_IL_OSTORE_AUX);
       }
       if (INPLACE) {
         // the next pass's first DMA pieces land in these buffers: every wave must have read its rows back
@@ -697,8 +709,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       }
     } else {
       T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
-      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
-      const int ooff = my_row * (int)p.os_n * 2 + hi * 8;
+      auto o_rs = rsrc_at(obase, p.o_bytes, WIN ? (unsigned long long)q0 * (unsigned long long)p.os_n * 2ull : 0ull);
+      const int ooff = (my_row - (WIN ? q0 : 0)) * (int)p.os_n * 2 + hi * 8;
       typedef __attribute__((ext_vector_type(4))) T t4;
 #pragma unroll
       for (int d = 0; d < DT; ++d) {

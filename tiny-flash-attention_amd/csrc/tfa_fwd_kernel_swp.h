@@ -79,9 +79,9 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel_swp(const KArgs p) {
   const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
   const T* kbase = reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h;
   const T* vbase = reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h;
-  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, p.q_bytes, 0x00020000);
-  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
-  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
+  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, (unsigned)p.q_bytes, 0x00020000);
+  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (unsigned)p.k_bytes, 0x00020000);
+  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (unsigned)p.v_bytes, 0x00020000);
 
   int k_src[PPW], v_src[PPW];
 #pragma unroll
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel_swp(const KArgs p) {
     }
     if (F32OUT) {
       float* obase = reinterpret_cast<float*>(p.o) + b * p.os_b + h * p.os_h;
-      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
       const int ooff = my_row * (int)p.os_n * 4 + hi * 16;
 #pragma unroll
       for (int d = 0; d < DT; ++d)
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel_swp(const KArgs p) {
         }
     } else {
       T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
-      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+      auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
       const int ooff = my_row * (int)p.os_n * 2 + hi * 8;
       typedef __attribute__((ext_vector_type(4))) T t4;
 #pragma unroll

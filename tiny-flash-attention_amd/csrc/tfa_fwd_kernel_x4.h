@@ -192,9 +192,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
   const T* kbase = reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h;
   const T* vbase = reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h;
-  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, p.q_bytes, 0x00020000);
-  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.k_bytes, 0x00020000);
-  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, p.v_bytes, 0x00020000);
+  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, (unsigned)p.q_bytes, 0x00020000);
+  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (unsigned)p.k_bytes, 0x00020000);
+  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (unsigned)p.v_bytes, 0x00020000);
 
   // per-lane DMA source offsets of this wave's pieces (tile 0); the K swizzle and the V sub-tile order are applied to the
   // SOURCE address, the LDS destination of piece pc is pc * 1024 + lane * 16 (tfa_fwd_kernel_dma.h)
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       }
       if constexpr (F32OUT) {
         float* obase = reinterpret_cast<float*>(p.o) + b * p.os_b + h * p.os_h;
-        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
         const int ooff = my_row * (int)p.os_n * 4 + hi * 16;
         static_for<0, DT * 4>([&](auto c_c) {
           constexpr int c = decltype(c_c)::value, R = (rb * DT + c / 4) * 16 + (c % 4) * 4;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         // lane, 32 different rows per instruction.  Instead the wave transposes each 32 x D block through its own slice
         // of the epilogue region (16-byte chunk index XOR row, as for K) and writes whole rows: 1 KiB contiguous per store.
         T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
-        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
         typedef __attribute__((ext_vector_type(4))) T t4;
         int qix = qi, lanex = lane;                  // (through an empty asm: none of the addresses below may be hoisted out of the pass loop)
         asm volatile("" : "+v"(qix), "+v"(lanex));
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by this wave's next epilogue only
       } else {
         T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
-        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, p.o_bytes, 0x00020000);
+        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
         const int ooff = my_row * (int)p.os_n * 2 + hi * 8;
         typedef __attribute__((ext_vector_type(4))) T t4;
         static_for<0, DT * 4>([&](auto c_c) {

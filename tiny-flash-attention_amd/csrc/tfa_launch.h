@@ -114,6 +114,12 @@ static inline bool supports_padded_d(int variant) {
   return (vf & VF_DMA) && !(vf & (VF_SWP | VF_W64));
 }
 
+// kernels that address a (b,h) slice through windowed descriptors (rsrc_at): the slice may exceed 2 GiB
+static inline bool windowed_slices(int variant) {
+  if (variant < 0 || variant >= kNumVariants) return false;
+  return variant == kDefaultVariant || variant == kSmallGridVariant;   // the dispatched il kernels have a windowed instantiation
+}
+
 static inline int block_m_of(int variant) { return kVariants[variant].nw * 32 * kVariants[variant].rb; }
 static inline bool uses_dma(int variant) { return (kVariants[variant].vf & VF_DMA) != 0; }
 static inline bool pairs_causal(int variant) { return (kVariants[variant].vf & VF_PAIR) != 0; }
