@@ -16,6 +16,7 @@ ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--warm", type=float, default=1.0)
+ap.add_argument("--check", action="store_true", help="also compare every build's output bits with the first build's")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 P = C.POINTER(_lib.TfaFwdParams)
@@ -49,4 +50,14 @@ for cfg in a.cfgs.split(","):
             st = L.tfa_fwd_time(C.byref(p), 3, a.iters, s, C.byref(ms))
             assert st == 0, (name, st)
             res[name].append(fl.value / (ms.value * 1e-3) / 1e12)
-    print(f"{cfg:7s}", "  ".join(f"{n}: {sorted(x)[len(x) // 2]:7.1f}" for n, x in res.items()), flush=True)
+    same = ""
+    if a.check:
+        outs = []
+        for name, L, var in entries:
+            L.tfa_set_variant(var)
+            out.zero_(); lse.zero_()
+            assert L.tfa_fwd_time(C.byref(p), 0, 1, s, C.byref(ms)) == 0
+            torch.cuda.synchronize()
+            outs.append((out.clone(), lse.clone()))
+        same = "  bits: " + " ".join(f"{e[0]}={'same' if torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) else 'DIFF'}" for e, o in zip(entries, outs))
+    print(f"{cfg:7s}", "  ".join(f"{n}: {sorted(x)[len(x) // 2]:7.1f}" for n, x in res.items()) + same, flush=True)

@@ -1,11 +1,15 @@
 #!/bin/bash
-# usage: tools/build_il_variant.sh NAME "-DTFA_IL_...=..." : lib_NAME/libtfa_hip.so = product objects + the bf16/D=128 il unit
-# rebuilt with the given flags (for tools/ab_multi.py name=path:30).
+# usage: [UNITS="bf16_128 f16_64"] tools/build_il_variant.sh NAME "-DTFA_IL_...=..." : lib_NAME/libtfa_hip.so = product objects + the listed
+# il units (default bf16_128) rebuilt with the given flags (for tools/ab_multi.py name=path:30).
 set -e
 cd "$(dirname "$0")/../tiny-flash-attention_amd/csrc"
-NAME=$1; FLAGS=$2
+NAME=$1; FLAGS=$2; UNITS=${UNITS:-bf16_128}
 mkdir -p ../build_$NAME ../lib_$NAME
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-function -Wno-inline-asm -fno-gpu-rdc -mllvm -amdgpu-early-inline-all=true $FLAGS -c tfa_fwd_inst_bf16_128.hip -o ../build_$NAME/tfa_fwd_inst_bf16_128.o 2>/dev/null
-objs=$(ls ../build/*.o | grep -v tfa_fwd_inst_bf16_128)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs ../build_$NAME/tfa_fwd_inst_bf16_128.o -o ../lib_$NAME/libtfa_hip.so
+objs=$(ls ../build/*.o)
+for u in $UNITS; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-function -Wno-inline-asm -fno-gpu-rdc -mllvm -amdgpu-early-inline-all=true $FLAGS -c tfa_fwd_inst_$u.hip -o ../build_$NAME/tfa_fwd_inst_$u.o 2>/dev/null &
+  objs=$(echo "$objs" | grep -v "tfa_fwd_inst_$u.o")
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs ../build_$NAME/*.o -o ../lib_$NAME/libtfa_hip.so
 echo "built lib_$NAME"
