@@ -24,6 +24,12 @@ GROUPS = [
 
 
 def main():
+    if sys.argv[1] == "--rederive":                  # rewrite <prefix>.txt from <prefix>.json (no GPU needed)
+        for pre in sys.argv[2:]:
+            res = json.load(open(pre + ".json"))
+            head = open(pre + ".txt").read().splitlines()
+            write_txt(pre, res, head[0].split("'")[1], head[1].split("command: ", 1)[1])
+        return
     out = sys.argv[1]
     cmd = sys.argv[sys.argv.index("--") + 1:]
     kern_filter = os.environ.get("KERNEL_FILTER", "fwd_kernel")
@@ -50,16 +56,31 @@ def main():
             res[k] = acc[k] / cnt[k]
         res.setdefault("dispatches", max(cnt.values()) if cnt else 0)
     json.dump(res, open(out + ".json", "w"), indent=1, sort_keys=True)
+    write_txt(out, res, kern_filter, " ".join(cmd))
+
+
+N_SIMD, N_XCD, MFMA_CYCLES = 1024, 8, 32   # MI355X: 256 CUs x 4 SIMDs in 8 XCDs; v_mfma_f32_32x32x16_{bf16,f16} holds the pipe 32 cycles
+
+
+def write_txt(out, res, kern_filter, cmd):
     with open(out + ".txt", "w") as f:
-        f.write("# per-launch means over dispatches of kernels matching '%s'\n# command: %s\n" % (kern_filter, " ".join(cmd)))
+        f.write("# per-launch means over dispatches of kernels matching '%s'\n# command: %s\n" % (kern_filter, cmd))
         for k in sorted(res):
             f.write(f"{k:34s} {res[k]}\n")
-        if "SQ_WAVE_CYCLES" in res and "SQ_VALU_MFMA_BUSY_CYCLES" in res:
-            f.write("\n# derived (per guide: SQ_* wave counters are quad-cycles, MFMA_BUSY is cycles)\n")
-            if res.get("SQ_BUSY_CYCLES"):
-                f.write(f"mfma_busy_frac_of_sq_busy          {res['SQ_VALU_MFMA_BUSY_CYCLES'] / res['SQ_BUSY_CYCLES']:.4f}\n")
-            if res.get("GRBM_GUI_ACTIVE"):
-                f.write(f"mfma_busy_per_simd / gui_active    {res['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * res['GRBM_GUI_ACTIVE']):.4f}\n")
+        gui = res.get("GRBM_GUI_ACTIVE")
+        if gui:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs (cfg3: 7.78e6 = 8 x 0.97e6 cycles = 0.52 ms at 1.88 GHz); the SQ
+            # counters are summed over all SIMDs.  SQ_VALU_MFMA_BUSY_CYCLES equals 32 x SQ_INSTS_MFMA exactly where it does
+            # not saturate (it is a 31-bit counter: cfg4 reads 2147483648), so the instruction count is the robust source.
+            f.write("\n# derived: matrix-pipe busy fraction over the whole launch, per SIMD = 32 cycles x MFMA instructions / 1024 SIMDs\n"
+                    "#          divided by the launch's shader cycles = GRBM_GUI_ACTIVE / 8 XCDs\n")
+            if res.get("SQ_INSTS_MFMA"):
+                f.write(f"mfma_pipe_busy_from_insts          {MFMA_CYCLES * res['SQ_INSTS_MFMA'] / N_SIMD / (gui / N_XCD):.4f}\n")
+            b = res.get("SQ_VALU_MFMA_BUSY_CYCLES")
+            if b and b < 2147483648.0:
+                f.write(f"mfma_pipe_busy_from_busy_cycles    {b / N_SIMD / (gui / N_XCD):.4f}\n")
+            if res.get("SQ_INSTS_VALU") and res.get("SQ_INSTS_MFMA"):
+                f.write(f"valu_insts_per_mfma (non-MFMA)     {(res['SQ_INSTS_VALU'] - res['SQ_INSTS_MFMA']) / res['SQ_INSTS_MFMA']:.2f}\n")
     print(open(out + ".txt").read())
 
 
