@@ -641,6 +641,11 @@ def test_dropin_extension_module_attention_cuda(tfa, oracle, dev):
     assert (out.float().cpu() - ref).abs().max().item() <= 2e-3
     base = torch.matmul(torch.softmax((torch.matmul(qd, kd.transpose(2, 3)) / math.sqrt(64)).float(), dim=-1).half(), vd)   # self_attention.py:21-28
     assert torch.allclose(base, out, rtol=0, atol=1e-2)
+    # the shape the reference's own script runs (self_attention.py:31-33): BS, HEAD, SEQLEN, DIM = 1000, 1, 64, 64, fp16
+    q2, k2, v2 = oracle.make_inputs(1000, 1, 64, 64, torch.float16, seed=15)
+    out2 = flash_attention_v2_cuda(q2.to(dev), k2.to(dev), v2.to(dev))
+    ref2 = oracle.exact64(q2, k2, v2, False, 1.0 / math.sqrt(64), p_round=torch.float16)
+    assert (out2.float().cpu() - ref2).abs().max().item() <= 2e-3
     with pytest.raises(RuntimeError, match="q must be a CUDA tensor"):
         flash_attention_v2_cuda(q, k, v)
     with pytest.raises(RuntimeError, match="must be float16 or bfloat16"):
