@@ -30,6 +30,8 @@ def dev():
     (torch.float16, 1, 2, 2, 700, 256, 64, True, 4),         # chunks that many rows cannot see at all
     (torch.float16, 1, 2, 1, 333, 777, 64, False, 5),
     (torch.bfloat16, 1, 1, 1, 1, 2048, 128, True, 8),        # decode-like: one query row, 8 key chunks
+    (torch.bfloat16, 1, 2, 2, 300, 900, 96, True, 3),        # head dims inside the 128- and 64-wide kernels
+    (torch.float16, 2, 2, 1, 200, 500, 32, False, 2),
 ])
 def test_splitkv_matches_one_pass(oracle, dev, variant, dtype, B, H, Hk, Nq, Nk, D, causal, splits):
     from tiny_flash_attention_amd import _lib, ops
@@ -64,8 +66,15 @@ def test_splitkv_matches_one_pass(oracle, dev, variant, dtype, B, H, Hk, Nq, Nk,
 def test_merge_kernel_vs_oracle(oracle, dev):
     from tiny_flash_attention_amd import ops
 
+    for D in (128, 96, 24):
+        _merge_case(oracle, dev, D)
+
+
+def _merge_case(oracle, dev, D):
+    from tiny_flash_attention_amd import ops
+
     g = torch.Generator().manual_seed(3)
-    P, B, H, N, D = 5, 2, 3, 77, 128
+    P, B, H, N = 5, 2, 3, 77
     o_parts = torch.empty((P, B, H, N, D)).normal_(0, 1, generator=g)
     lse_parts = torch.empty((P, B, H, N)).normal_(0, 3, generator=g)
     lse_parts[1, :, :, :10] = math.inf            # empty parts for some rows

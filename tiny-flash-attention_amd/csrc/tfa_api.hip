@@ -172,7 +172,7 @@ const char* tfa_strerror(int status) {
     case TFA_OK: return "success";
     case TFA_ERR_NULL: return "tfa: a required pointer is NULL";
     case TFA_ERR_DTYPE: return "tfa: unsupported dtype (q/k/v must be fp16 or bf16; out must match or be fp32)";
-    case TFA_ERR_HEAD_DIM: return "tfa: unsupported head dim (forward: multiples of 8 up to 256; split-KV, merge and backward: 64, 128)";
+    case TFA_ERR_HEAD_DIM: return "tfa: unsupported head dim (forward: multiples of 8 up to 256; split-KV: multiples of 8 up to 128; merge: multiples of 4 up to 256; backward: 64, 128)";
     case TFA_ERR_SHAPE: return "tfa: bad shape (sizes must be positive and H % Hk == 0)";
     case TFA_ERR_STRIDE: return "tfa: bad stride (must be >=0, rows 16-byte aligned and non-overlapping; 768 rows of a (b,h) slice must span < 2 GiB, the whole slice for split-KV / backward)";
     case TFA_ERR_ALIGN: return "tfa: base pointers must be 16-byte aligned";
@@ -233,7 +233,7 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   int ns = 0, ch = 0;
   int st = splitkv_geometry(p, splits, &ns, &ch);
   if (st != TFA_OK) return st;
-  if (p->D != 64 && p->D != 128) return TFA_ERR_HEAD_DIM;   // the merge kernel's row layout
+  if (p->D < 8 || p->D > 128 || (p->D % 8) != 0) return TFA_ERR_HEAD_DIM;   // the LDS-DMA kernel: 64 and 128 wide, any valid width inside
   if (!workspace || ((uintptr_t)workspace & 15)) return workspace ? TFA_ERR_ALIGN : TFA_ERR_NULL;
   // the merge writes contiguous rows: out must be a contiguous (B,H,Nq,D) tensor
   if (p->o_stride[2] != p->D || p->o_stride[1] != (int64_t)p->Nq * p->D || p->o_stride[0] != (int64_t)p->H * p->Nq * p->D) return TFA_ERR_STRIDE;
@@ -258,9 +258,9 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   hipError_t e;
   const bool causal = p->is_causal != 0;
   if (p->dtype == TFA_BF16)
-    e = (p->D == 128) ? tfa::launch_fwd<__bf16, 128>(a, causal, true, variant, s, nullptr, false) : tfa::launch_fwd<__bf16, 64>(a, causal, true, variant, s, nullptr, false);
+    e = (p->D > 64) ? tfa::launch_fwd<__bf16, 128>(a, causal, true, variant, s, nullptr, false) : tfa::launch_fwd<__bf16, 64>(a, causal, true, variant, s, nullptr, false);
   else
-    e = (p->D == 128) ? tfa::launch_fwd<_Float16, 128>(a, causal, true, variant, s, nullptr, false) : tfa::launch_fwd<_Float16, 64>(a, causal, true, variant, s, nullptr, false);
+    e = (p->D > 64) ? tfa::launch_fwd<_Float16, 128>(a, causal, true, variant, s, nullptr, false) : tfa::launch_fwd<_Float16, 64>(a, causal, true, variant, s, nullptr, false);
   if (e != hipSuccess) return (int)e;
   return tfa_merge(ws_o, ws_l, ns, rows, p->D, rows * p->D, rows, p->out, p->out_dtype, p->lse, stream);
 }

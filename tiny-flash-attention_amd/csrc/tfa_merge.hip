@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* __restrict__ o_
 extern "C" int tfa_merge(const float* o_parts, const float* lse_parts, int nparts, int64_t rows, int D, int64_t o_part_stride,
                          int64_t lse_part_stride, void* out, int out_dtype, float* lse_out, void* stream) {
   if (!o_parts || !lse_parts || !out) return TFA_ERR_NULL;
-  if (nparts <= 0 || rows <= 0 || (D != 64 && D != 128)) return TFA_ERR_SHAPE;
+  if (nparts <= 0 || rows <= 0) return TFA_ERR_SHAPE;
+  if (D < 4 || D > 256 || (D % 4) != 0) return TFA_ERR_HEAD_DIM;   // a thread owns one 16-byte chunk of fp32
   if (o_part_stride < rows * D || lse_part_stride < rows) return TFA_ERR_STRIDE;
   if (((uintptr_t)o_parts | (uintptr_t)out) & 15) return TFA_ERR_ALIGN;
   if ((o_part_stride * 4) % 16 != 0) return TFA_ERR_STRIDE;
