@@ -67,7 +67,7 @@ enum tfa_status {
   TFA_ERR_NULL = -1,          /* a required pointer is NULL */
   TFA_ERR_DTYPE = -2,         /* dtype not in {F16,BF16}; out_dtype not in {dtype,F32} */
   TFA_ERR_HEAD_DIM = -3,      /* forward: D not a multiple of 8 in [8,256]; split-KV: not a multiple of 8 in [8,128]; merge: not a multiple
-                               * of 4 in [4,256]; backward: D not in {64,128} */
+                               * of 4 in [4,256]; backward: not a multiple of 8 in [8,128] */
   TFA_ERR_SHAPE = -4,         /* B,H,Hk,Nq,Nk <= 0 or H % Hk != 0 */
   TFA_ERR_STRIDE = -5,        /* a stride is negative, not 16-byte aligned, rows overlap, or 768 rows of a (b,h) slice span 2 GiB
                                * (tfa_fwd with D <= 128 switches to per-block / per-tile descriptor windows when a slice is larger,

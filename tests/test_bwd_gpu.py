@@ -89,6 +89,9 @@ BWD_SHAPES = [
     (torch.float16, 1, 2, 1, 1, 500, 64, True),          # single query row (decode-like)
     (torch.bfloat16, 1, 1, 1, 77, 65, 64, False),
     (torch.bfloat16, 3, 2, 2, 513, 513, 64, True),
+    (torch.bfloat16, 1, 2, 2, 300, 300, 96, True),       # head dims inside the 128- and 64-wide kernels (columns beyond D read as zeros)
+    (torch.float16, 2, 2, 1, 200, 333, 32, False),
+    (torch.bfloat16, 1, 1, 1, 130, 130, 72, True),
 ]
 
 

@@ -13,10 +13,10 @@ template <> hipError_t launch_bwd<__bf16, 64>(const BArgs&, int, int, bool, bool
 template <> hipError_t launch_bwd<__bf16, 128>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_bwd<_Float16, 64>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_bwd<_Float16, 128>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
-template <> hipError_t launch_delta<__bf16, 64>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, hipStream_t, bool);
-template <> hipError_t launch_delta<__bf16, 128>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, hipStream_t, bool);
-template <> hipError_t launch_delta<_Float16, 64>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, hipStream_t, bool);
-template <> hipError_t launch_delta<_Float16, 128>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, hipStream_t, bool);
+template <> hipError_t launch_delta<__bf16, 64>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
+template <> hipError_t launch_delta<__bf16, 128>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
+template <> hipError_t launch_delta<_Float16, 64>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
+template <> hipError_t launch_delta<_Float16, 128>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
 }  // namespace tfa
 
 namespace {
@@ -49,7 +49,7 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   if (!p->q || !p->k || !p->v || !p->out || !p->dout || !p->lse || !p->dq || !p->dk || !p->dv || !p->delta) return TFA_ERR_NULL;
   if (p->dtype != TFA_F16 && p->dtype != TFA_BF16) return TFA_ERR_DTYPE;
   if (p->grad_dtype != p->dtype && p->grad_dtype != TFA_F32) return TFA_ERR_DTYPE;
-  if (p->D != 64 && p->D != 128) return TFA_ERR_HEAD_DIM;
+  if (p->D < 8 || p->D > 128 || (p->D % 8) != 0) return TFA_ERR_HEAD_DIM;   // kernels are 64 and 128 wide; BArgs::dv = the valid part
   if (p->B <= 0 || p->H <= 0 || p->Hk <= 0 || p->Nq <= 0 || p->Nk <= 0 || p->H % p->Hk != 0) return TFA_ERR_SHAPE;
   if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
   const int esz = 2, gsz = (p->grad_dtype == TFA_F32) ? 4 : 2;
@@ -73,6 +73,8 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   if (!slice_bytes(p->Nq, p->o_stride[2], p->D, esz, &ob)) return TFA_ERR_STRIDE;
   a.lse = p->lse; a.delta = p->delta;
   a.B = p->B; a.H = p->H; a.Hk = p->Hk; a.Nq = p->Nq; a.Nk = p->Nk;
+  a.dv = p->D;
+  const bool wide = p->D > 64;
   a.scale = p->softmax_scale;
   a.scale_log2 = p->softmax_scale * 1.4426950408889634f;
   const bool causal = p->is_causal != 0, f32 = p->grad_dtype == TFA_F32;
@@ -87,9 +89,9 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
     if (grid >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
     hipError_t e;
     if (p->dtype == TFA_BF16)
-      e = (p->D == 128) ? tfa::launch_bwd<__bf16, 128>(m, mode, (int)grid, causal, f32, s, dry) : tfa::launch_bwd<__bf16, 64>(m, mode, (int)grid, causal, f32, s, dry);
+      e = wide ? tfa::launch_bwd<__bf16, 128>(m, mode, (int)grid, causal, f32, s, dry) : tfa::launch_bwd<__bf16, 64>(m, mode, (int)grid, causal, f32, s, dry);
     else
-      e = (p->D == 128) ? tfa::launch_bwd<_Float16, 128>(m, mode, (int)grid, causal, f32, s, dry) : tfa::launch_bwd<_Float16, 64>(m, mode, (int)grid, causal, f32, s, dry);
+      e = wide ? tfa::launch_bwd<_Float16, 128>(m, mode, (int)grid, causal, f32, s, dry) : tfa::launch_bwd<_Float16, 64>(m, mode, (int)grid, causal, f32, s, dry);
     return (int)e;
   };
 
@@ -100,11 +102,11 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
     const long long rows = (long long)p->B * p->H * p->Nq;
     hipError_t e;
     if (p->dtype == TFA_BF16)
-      e = (p->D == 128) ? tfa::launch_delta<__bf16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, s, dry)
-                        : tfa::launch_delta<__bf16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, s, dry);
+      e = wide ? tfa::launch_delta<__bf16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
+               : tfa::launch_delta<__bf16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry);
     else
-      e = (p->D == 128) ? tfa::launch_delta<_Float16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, s, dry)
-                        : tfa::launch_delta<_Float16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, s, dry);
+      e = wide ? tfa::launch_delta<_Float16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
+               : tfa::launch_delta<_Float16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry);
     if (e != hipSuccess) return (int)e;
   }
   int st = launch(tfa::BWD_DQ, p->dq, p->dq_stride, p->Nq, p->H);

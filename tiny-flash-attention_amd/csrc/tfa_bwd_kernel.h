@@ -38,6 +38,8 @@ struct BArgs {
   const float* lse;          // (B,H,Nq) natural-log LSE from the forward
   const float* delta;        // (B,H,Nq) rowsum(dO o O)
   int B, H, Hk, Nq, Nk;
+  int dv;                    // valid head dim (multiple of 8, <= the kernel's width D): 16-byte chunks beyond it are read as zeros
+                             // (their offsets point out of the descriptor's range, TFA_OOB) and never stored
   int nrb;                   // 256-row resident blocks per (b, resident head)
   float scale, scale_log2;
 };
@@ -146,17 +148,19 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
       if (UNI) {                                     // unified row-major image
         const int row = pc * (1024 / (D * 2)) + lane / CPR;
         const int cpos = lane % CPR;
-        src[img][i] = row * sn * 2 + ((cpos ^ u_swz<D>(row)) << 4);
+        const int ch = cpos ^ u_swz<D>(row);
+        src[img][i] = ch * 8 < p.dv ? row * sn * 2 + (ch << 4) : (int)TFA_OOB;
       } else if (img != IMG_TR) {                    // K layout
         const int row = pc * (1024 / (D * 2)) + lane / CPR;
         const int cpos = lane % CPR;
-        src[img][i] = row * sn * 2 + ((cpos ^ k_swz<D>(row)) << 4);
+        const int ch = cpos ^ k_swz<D>(row);
+        src[img][i] = ch * 8 < p.dv ? row * sn * 2 + (ch << 4) : (int)TFA_OOB;
       } else {                                       // V layout
         const int o = pc * 1024 + lane * 16;
         const int sub = o >> 9, R = (o >> 6) & 7, pcs = (o >> 4) & 3;
         const int dt = sub % DT, sh = sub / DT;
         const int row = 16 * (sh >> 1) + 4 * (sh & 1) + 8 * (R >> 2) + (R & 3);
-        src[img][i] = row * sn * 2 + ((dt * 4 + pcs) << 4);
+        src[img][i] = (dt * 4 + pcs) * 8 < p.dv ? row * sn * 2 + ((dt * 4 + pcs) << 4) : (int)TFA_OOB;
       }
     }
   }
@@ -184,14 +188,14 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
     auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, x1.bytes, 0x00020000);
     const int off1 = my_row * (int)x1.s_n * 2 + hi * 16;
 #pragma unroll
-    for (int s = 0; s < DS; ++s) r1f[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs1, off1 + s * 32, 0, 0));
+    for (int s = 0; s < DS; ++s) r1f[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs1, (2 * s + hi) * 8 < p.dv ? off1 + s * 32 : (int)TFA_OOB, 0, 0));
     if (NEED_DP) {
       const BTensor& x2 = KEYS_RES ? p.v : p.dout;
       const T* b2 = reinterpret_cast<const T*>(x2.p) + b * x2.s_b + hr * x2.s_h;
       auto rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)b2, 0, x2.bytes, 0x00020000);
       const int off2 = my_row * (int)x2.s_n * 2 + hi * 16;
 #pragma unroll
-      for (int s = 0; s < DS; ++s) r2f[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs2, off2 + s * 32, 0, 0));
+      for (int s = 0; s < DS; ++s) r2f[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs2, (2 * s + hi) * 8 < p.dv ? off2 + s * 32 : (int)TFA_OOB, 0, 0));
     }
   }
   float lse2_lane = 0.f, delta_lane = 0.f;           // dQ: statistics of the lane's own query row
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         f32x4 v4 = {acc[d][4 * g4 + 0] * osc, acc[d][4 * g4 + 1] * osc, acc[d][4 * g4 + 2] * osc, acc[d][4 * g4 + 3] * osc};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), g_rs, goff + (d * 32 + g4 * 8) * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), g_rs, d * 32 + g4 * 8 + hi * 4 < p.dv ? goff + (d * 32 + g4 * 8) * 4 : (int)TFA_OOB, 0, 0);
       }
   } else {
     T* gb = reinterpret_cast<T*>(p.grad) + b * p.gs_b + hr * p.gs_h;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         t4 v4 = {(T)(acc[d][4 * g4 + 0] * osc), (T)(acc[d][4 * g4 + 1] * osc), (T)(acc[d][4 * g4 + 2] * osc), (T)(acc[d][4 * g4 + 3] * osc)};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), g_rs, goff + (d * 32 + g4 * 8) * 2, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), g_rs, d * 32 + g4 * 8 + hi * 4 < p.dv ? goff + (d * 32 + g4 * 8) * 2 : (int)TFA_OOB, 0, 0);
       }
   }
 }
@@ -375,14 +379,14 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
 // delta[b,h,i] = sum_d dO[b,h,i,d] * O[b,h,i,d]  (fp32).  LPR lanes per row, 8 elements (16 bytes) per lane.
 template <typename T, int D>
 __global__ __launch_bounds__(256) void bwd_delta_kernel(const void* o, const void* dout, float* delta, long long os_b, long long os_h, long long os_n,
-                                                       long long ds_b, long long ds_h, long long ds_n, int H, int Nq, long long rows) {
+                                                       long long ds_b, long long ds_h, long long ds_n, int H, int Nq, long long rows, int dv) {
   constexpr int LPR = D / 8;
   typedef __attribute__((ext_vector_type(8))) T t8;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long row = gid / LPR;
   const int c = (int)(gid % LPR);
   float acc = 0.f;
-  if (row < rows) {
+  if (row < rows && c * 8 < dv) {
     const long long bh = row / Nq;
     const int i = (int)(row - bh * Nq);
     const int b = (int)(bh / H), h = (int)(bh - (long long)b * H);

@@ -9,5 +9,5 @@ template <typename T, int D>
 hipError_t launch_bwd(const BArgs& a, int mode, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);
 template <typename T, int D>
 hipError_t launch_delta(const void* o, const void* dout, float* delta, const long long* os, const long long* ds, int H, int Nq, long long rows,
-                        hipStream_t stream, bool dry);
+                        int dv, hipStream_t stream, bool dry);
 }  // namespace tfa
