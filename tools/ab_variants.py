@@ -8,13 +8,16 @@ from tiny_flash_attention_amd import _lib, ops
 CFG = {"cfg2": (4, 8, 1024, 64, torch.float16, False), "cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096, 128, torch.bfloat16, False),
        "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg4c": (1, 16, 16384, 128, torch.bfloat16, True), "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),
        "d64": (4, 32, 4096, 64, torch.float16, False), "d64c": (4, 32, 4096, 64, torch.float16, True), "n2k": (8, 32, 2048, 128, torch.bfloat16, True),
-       "n1k": (16, 32, 1024, 128, torch.bfloat16, True)}
+       "n1k": (16, 32, 1024, 128, torch.bfloat16, True), "cfg3h16": (4, 16, 4096, 128, torch.bfloat16, True),
+       "n8k": (2, 32, 8192, 128, torch.bfloat16, True)}
 ap = argparse.ArgumentParser()
 ap.add_argument("--variants", default="30,33")
 ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--warm", type=float, default=1.0, help="seconds of pre-conditioning launches before the rounds")
+ap.add_argument("--dbgs", default="", help="comma list of tfa_debug_set_flags values: the A/B axis becomes (first variant, flags) instead of variants")
+ap.add_argument("--check", action="store_true", help="compare every arm's output bits with the first arm's")
 ap.add_argument("--data", default="normal", choices=["normal", "zeros", "ones", "small"],
                 help="input values: the reference's normal(0,0.5), all zeros, all ones, or normal(0,0.01) — same instruction stream, "
                      "different switching activity (the DVFS give-back experiment of MI355X_MICROARCH.md)")
@@ -22,6 +25,7 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 L = _lib.lib()
 vs = [int(x) for x in a.variants.split(",")]
+arms = [(vs[0], int(f)) for f in a.dbgs.split(",")] if a.dbgs else [(v, 0) for v in vs]
 import time
 for cfg in a.cfgs.split(","):
     B, H, N, D, dt, causal = CFG[cfg]
@@ -44,11 +48,22 @@ for cfg in a.cfgs.split(","):
     _lib.set_variant(vs[0])
     while time.time() - t0 < a.warm:
         _lib.check(L.tfa_fwd_time(C.byref(p), 0, 50, s, C.byref(ms)))
-    res = {v: [] for v in vs}
+    res = {arm: [] for arm in arms}
     for r in range(a.rounds):
-        for vv in vs:
-            _lib.set_variant(vv)
+        for arm in arms:
+            _lib.set_variant(arm[0]); _lib.debug_set_flags(arm[1])
             _lib.check(L.tfa_fwd_time(C.byref(p), 3, a.iters, s, C.byref(ms)))
-            res[vv].append(fl.value / (ms.value * 1e-3) / 1e12)
-    _lib.set_variant(-1)
-    print(cfg, f"[{a.data}]", " ".join(f"v{vv}: med {sorted(res[vv])[len(res[vv]) // 2]:7.1f} max {max(res[vv]):7.1f} TF" for vv in vs), flush=True)
+            res[arm].append(fl.value / (ms.value * 1e-3) / 1e12)
+    same = ""
+    if a.check:
+        outs = []
+        for arm in arms:
+            _lib.set_variant(arm[0]); _lib.debug_set_flags(arm[1])
+            out.zero_(); lse.zero_()
+            _lib.check(L.tfa_fwd_time(C.byref(p), 0, 1, s, C.byref(ms)))
+            torch.cuda.synchronize()
+            outs.append((out.clone(), lse.clone()))
+        same = " bits: " + " ".join("same" if torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) else "DIFF" for o in outs)
+    _lib.set_variant(-1); _lib.debug_set_flags(0)
+    name = lambda arm: f"v{arm[0]}" + (f"/dbg{arm[1]:#x}" if a.dbgs else "")
+    print(cfg, f"[{a.data}]", " ".join(f"{name(arm)}: med {sorted(res[arm])[len(res[arm]) // 2]:7.1f} max {max(res[arm]):7.1f} TF" for arm in arms) + same, flush=True)
