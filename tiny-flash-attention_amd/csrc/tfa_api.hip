@@ -17,9 +17,6 @@ template <> hipError_t launch_fwd<__bf16, 64>(const KArgs&, bool, bool, int, hip
 template <> hipError_t launch_fwd<__bf16, 128>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
 template <> hipError_t launch_fwd<_Float16, 64>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
 template <> hipError_t launch_fwd<_Float16, 128>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
-// defined in tfa_x4_inst_<dtype>_256.hip: the kernel for head dims above 128
-template <> hipError_t launch_x4_unit<__bf16, 256>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
-template <> hipError_t launch_x4_unit<_Float16, 256>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
 }  // namespace tfa
 
 namespace {

@@ -102,9 +102,23 @@ static inline hipError_t launch_common(Kern kern, std::atomic<unsigned long long
   return hipGetLastError();
 }
 
-// defined in tfa_x4_inst_<dtype>_<D>.hip; ablate != 0 selects a timing-only ablation (EXPERIMENTAL builds)
+// The x4 kernel: one translation unit per (dtype, width, causal, output type) — tfa_x4_inst_<dtype>_<D>_c<0|1>_o<16|32>.hip —
+// each specialising launch_x4_piece; ablate != 0 selects a timing-only ablation (builds with -DTFA_X4_ABLATE).
+template <typename T, int D, bool CAUSAL, bool F32OUT>
+hipError_t launch_x4_piece(const KArgs& a, int ablate, hipStream_t stream, LaunchGeom* geom, bool dry);
+#define TFA_X4_PIECES(T, D)                                                                                   \
+  template <> hipError_t launch_x4_piece<T, D, false, false>(const KArgs&, int, hipStream_t, LaunchGeom*, bool); \
+  template <> hipError_t launch_x4_piece<T, D, false, true>(const KArgs&, int, hipStream_t, LaunchGeom*, bool);  \
+  template <> hipError_t launch_x4_piece<T, D, true, false>(const KArgs&, int, hipStream_t, LaunchGeom*, bool);  \
+  template <> hipError_t launch_x4_piece<T, D, true, true>(const KArgs&, int, hipStream_t, LaunchGeom*, bool);
+TFA_X4_PIECES(__bf16, 64) TFA_X4_PIECES(__bf16, 128) TFA_X4_PIECES(__bf16, 256)
+TFA_X4_PIECES(_Float16, 64) TFA_X4_PIECES(_Float16, 128) TFA_X4_PIECES(_Float16, 256)
+#undef TFA_X4_PIECES
 template <typename T, int D>
-hipError_t launch_x4_unit(const KArgs& a, bool causal, bool f32out, int ablate, hipStream_t stream, LaunchGeom* geom, bool dry);
+static inline hipError_t launch_x4_unit(const KArgs& a, bool causal, bool f32out, int ablate, hipStream_t stream, LaunchGeom* geom, bool dry) {
+  if (causal) return f32out ? launch_x4_piece<T, D, true, true>(a, ablate, stream, geom, dry) : launch_x4_piece<T, D, true, false>(a, ablate, stream, geom, dry);
+  return f32out ? launch_x4_piece<T, D, false, true>(a, ablate, stream, geom, dry) : launch_x4_piece<T, D, false, false>(a, ablate, stream, geom, dry);
+}
 
 // kernels that honour KArgs::dv (head dims below the compiled width: LDS-DMA lanes / Q loads / O stores of the missing
 // 16-byte chunks go out of range): the LDS-DMA kernel, the il kernels and the x4 kernel
