@@ -227,6 +227,27 @@ def tiled_emulation_lazy(q, k, v, is_causal, softmax_scale, block_n=64, group=32
     return out
 
 
+def ksplit_emulation(q, k, v, softmax_scale, block_n=64, return_lse=False, **kw):
+    """Rounding points of the key-split kernel (VF_IL_KSPLIT in tiny-flash-attention_amd/csrc/tfa_fwd_kernel_il.h; non-causal):
+    two wave groups run ``tiled_emulation_lazy`` over the even and the odd ``block_n``-key tiles of the sequence and the two
+    partial results are combined by the split-KV rule (tiny_flash_attn.py:63-68 / README_zh.md:104-125 restated in
+    ``merge_partials``)."""
+    Nk = k.shape[2]
+    nt = (Nk + block_n - 1) // block_n
+    outs, lses = [], []
+    for g in (0, 1):
+        idx = [torch.arange(t * block_n, min((t + 1) * block_n, Nk)) for t in range(g, nt, 2)]
+        if not idx:
+            continue
+        idx = torch.cat(idx)
+        o, l = tiled_emulation_lazy(q, k.detach().cpu()[:, :, idx], v.detach().cpu()[:, :, idx], False, softmax_scale, block_n,
+                                    return_lse=True, **kw)
+        outs.append(o)
+        lses.append(l)
+    out, lse = merge_partials(torch.stack(outs), torch.stack(lses))
+    return (out, lse) if return_lse else out
+
+
 def partial_attn(q, k_chunk, v_chunk, is_causal, softmax_scale, kv_offset, nk_total):
     """fp32 partial attention of all queries over the key chunk [kv_offset, kv_offset+len) of a sequence of
     ``nk_total`` keys, causal mask against global positions (attn.cpp:121-124 with the chunk offset): returns

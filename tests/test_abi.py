@@ -84,7 +84,7 @@ def test_product_build_rejects_ab_arms():
     # the product library carries the dispatched kernels only (tfa_launch.h); the other table entries answer TFA_ERR_VARIANT
     L = _lib.lib()
     avail = [v for v in range(_lib.num_variants()) if _lib.variant_available(v)]
-    for v in (17, 30, 32, 33, 34):
+    for v in (17, 30, 32, 33, 34, 36):
         assert v in avail
     for v in range(_lib.num_variants()):
         if v not in avail:
@@ -200,11 +200,15 @@ def test_reference_named_extension_modules_import_and_reject_cpu_tensors(module,
 
 
 def test_variant_selection_is_introspectable_without_gpu():
-    # big grids -> the 8-wave issue-interleaved kernel, small grids -> its 4-wave form (128-row blocks, 2 workgroups per CU)
+    # big grids -> the 8-wave issue-interleaved kernel, small grids -> its 4-wave form (128-row blocks, 2 workgroups per CU);
+    # non-causal grids of at most one 128-row block per CU with >= 16 KV tiles -> the key-split form (BASELINE config 2)
     big = _lib.variant_for(4, 32, 32, 4096, 4096, 128, True)
-    small = _lib.variant_for(4, 8, 8, 1024, 1024, 64, False, _lib.TFA_F16)
-    assert _lib.variant_name(big).startswith("il8") and _lib.lazy_reference(big)
+    small = _lib.variant_for(4, 8, 8, 1024, 1024, 64, True, _lib.TFA_F16)
+    cfg2 = _lib.variant_for(4, 8, 8, 1024, 1024, 64, False, _lib.TFA_F16)
+    assert _lib.variant_name(big).startswith("il8-pair") and _lib.lazy_reference(big)
     assert _lib.variant_name(small).startswith("il4") and _lib.lazy_reference(small)
+    assert _lib.variant_name(cfg2).startswith("il8-ksplit") and _lib.lazy_reference(cfg2)
+    assert _lib.variant_name(_lib.variant_for(4, 8, 8, 512, 512, 64, False, _lib.TFA_F16)).startswith("il4")   # 8 tiles: not worth the merge
     _lib.set_variant(17)
     try:
         assert _lib.variant_for(4, 32, 32, 4096, 4096, 128, True) == 17     # a forced variant is reported as such

@@ -46,10 +46,15 @@ def tfa():
     _lib.set_variant(-1)
 
 
-def _need_variant(variant):
+KSPLIT = 36      # il8-ksplit-epi: non-causal only
+
+
+def _need_variant(variant, causal=False):
     """The product build carries the dispatched kernels only; A/B arms need `make EXPERIMENTAL=1` (tfa_launch.h)."""
     from tiny_flash_attention_amd import _lib
 
+    if variant == KSPLIT and causal:
+        pytest.skip("the key-split kernel is non-causal only (TFA_ERR_VARIANT otherwise: test_ksplit_*)")
     if variant >= 0 and not _lib.variant_available(variant):
         pytest.skip(f"kernel variant {variant} is an A/B arm: not in the product build (make EXPERIMENTAL=1)")
 
@@ -62,7 +67,10 @@ def check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype, var=None):
     if var is None:
         var = _lib.variant_for(q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3], causal)
     emulate = oracle.tiled_emulation_lazy if _lib.lazy_reference(var) else oracle.tiled_emulation
-    emu, lse_e = emulate(q, k, v, causal, sc, 64, return_lse=True)
+    if var == KSPLIT:                                   # two wave groups over the even / odd key tiles, merged
+        emu, lse_e = oracle.ksplit_emulation(q, k, v, sc, 64, return_lse=True)
+    else:
+        emu, lse_e = emulate(q, k, v, causal, sc, 64, return_lse=True)
     exact, lse_x = oracle.exact64(q, k, v, causal, sc, return_lse=True)
     A = oracle.abs_weighted(q, k, v, causal, sc)
     o16 = out16.float().cpu()
@@ -117,12 +125,12 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29, 30, 31, 32, 33, 35])
+@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29, 30, 31, 32, 33, 35, 36])
 @pytest.mark.parametrize("dtype,B,H,N,D,causal", SHAPES)
 def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
     from tiny_flash_attention_amd import _lib
 
-    _need_variant(variant)
+    _need_variant(variant, causal)
     _lib.set_variant(variant)
     try:
         run_case(tfa, oracle, dev, dtype, B, H, N, D, causal)
@@ -130,7 +138,7 @@ def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causa
         _lib.set_variant(-1)
 
 
-@pytest.mark.parametrize("variant", [-1, 17, 30, 31, 33, 35])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
+@pytest.mark.parametrize("variant", [-1, 17, 30, 31, 33, 35, 36])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
 @pytest.mark.parametrize("Nq,Nk,causal", [(128, 384, True), (384, 128, True), (100, 333, False), (1, 1000, True), (257, 64, False),
                                           (700, 1500, True), (1111, 1111, False)])
 def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
@@ -138,7 +146,7 @@ def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
     # (flash_attention_c/csrc/attn.cpp:121-124); (384,128,causal) has 256 EMPTY rows -> O=0, LSE=+inf
     from tiny_flash_attention_amd import _lib
 
-    _need_variant(variant)
+    _need_variant(variant, causal)
     _lib.set_variant(variant)
     try:
         run_case(tfa, oracle, dev, torch.bfloat16, 1, 4, Nq, 128, causal, Hk=2, Nk=Nk, seed=7)
@@ -573,6 +581,32 @@ def test_windowed_instantiation_returns_the_same_bits(tfa, dev, variant, causal)
             finally:
                 _lib.debug_set_flags(0)
             assert torch.equal(o0, o1) and torch.equal(l0, l1), (B, H, Hk, Nq, Nk, D, layout)
+    finally:
+        _lib.set_variant(-1)
+
+
+@pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D", [
+    (torch.float16, 4, 8, 8, 1024, 1024, 64),        # BASELINE config 2: 256 blocks of 128 rows = one per CU
+    (torch.bfloat16, 1, 8, 2, 512, 1000, 128),       # GQA; 16 tiles, the ragged last one (15) belongs to group 1
+    (torch.bfloat16, 2, 4, 4, 300, 961, 128),        # 16 tiles, the last holds ONE key
+    (torch.bfloat16, 1, 4, 4, 200, 1089, 128),       # 18 tiles, the ragged last one (17: one key) belongs to group 1 ... 1089 = 17*64 + 1
+    (torch.float16, 1, 16, 16, 128, 320, 64),        # 5 tiles: group 0 has 3, group 1 has 2 (the workgroup iterates 3 times)
+    (torch.bfloat16, 1, 2, 2, 77, 256, 96),          # padded head dim, ragged rows
+    (torch.float16, 1, 2, 2, 100, 40, 64),           # ONE tile: group 1 has nothing to do and contributes weight 0
+])
+def test_ksplit_small_noncausal_grids(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D):
+    """The key-split kernel (8 waves on one 128-row block, even / odd KV tiles per wave group, merged through LDS), forced
+    onto small non-causal problems; the dispatcher picks it by itself for grids of at most one 128-row block per CU with at
+    least 16 KV tiles.  Same tolerances as every other kernel (check(), with the split's own rounding points)."""
+    from tiny_flash_attention_amd import _lib
+
+    assert (_lib.variant_for(B, H, Hk, Nq, Nk, D, False) == KSPLIT) == (Nk >= 1024)
+    assert _lib.variant_for(B, H, Hk, Nq, Nk, D, True) != KSPLIT
+    _lib.set_variant(KSPLIT)
+    try:
+        run_case(tfa, oracle, dev, dtype, B, H, Nq, D, False, Hk=Hk, Nk=Nk, seed=41)
+        with pytest.raises(_lib.TfaError):               # forced onto a causal problem: refused, not silently wrong
+            run_case(tfa, oracle, dev, dtype, 1, 1, 128, D, True, seed=1)
     finally:
         _lib.set_variant(-1)
 

@@ -35,6 +35,9 @@ constexpr int VF_IL_PREF = 524288;       // the next pass's K(0)/V(0)/K(1)/Q are
 constexpr int VF_IL_SEAM = 2097152;      // causal pairs: the heavy pass's last two iterations already request the light pass's K(0), K(1), V(0)
                                          // (same head, same K/V: the tile stream simply continues across the seam) and its Q
                                          // fragments are requested before the epilogue: the second prologue finds everything on chip
+constexpr int VF_IL_KSPLIT = 1 << 25;    // small non-causal grids: the 8 waves work on ONE 128-row query block — waves 0-3 ("group 0") take the even
+                                         // KV tiles, waves 4-7 the odd ones, each group with its own K/V ring in LDS; group 1 hands its O, m, l
+                                         // to group 0 through LDS at the end.  Two waves per SIMD where 128-row workgroups alone would leave one.
 constexpr int VF_IL_WINDOWED = 1 << 24;  // K/V tiles through per-tile descriptors (rsrc_at): a (b,h) slice may exceed 2 GiB.  ~6 % slower (a fresh
                                          // descriptor per tile: ~14 SALU + the SGPR->VMEM wait states), so only launched when needed
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
@@ -121,12 +124,15 @@ template <typename T, int D, int NW, bool CAUSAL, bool F32OUT, int VF, int AB = 
 __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) void fwd_kernel_il(const KArgs p) {
   using E = Elem<T>;
   using X8 = typename E::x8;
-  constexpr int BM = NW * 32;
+  constexpr bool KSPLIT = (VF & VF_IL_KSPLIT) != 0;
+  constexpr int NWG = KSPLIT ? NW / 2 : NW;        // waves per query block (KSPLIT: per key-tile group)
+  constexpr int BM = NWG * 32;
+  static_assert(!KSPLIT || (!CAUSAL && !(VF & VF_PAIR) && (VF & VF_IL_EPI_INPLACE) && !(VF & (VF_IL_SEAM | VF_IL_PREF | VF_IL_WINDOWED))), "KSPLIT: non-causal, in-place epilogue");
   constexpr int BN = 64;
   constexpr int CPR = D / 8;
   constexpr int TILE_BYTES = BN * D * 2;
   constexpr int PIECES = TILE_BYTES / 1024;
-  constexpr int PPW = PIECES / NW;                 // DMA pieces per wave per tensor per tile
+  constexpr int PPW = PIECES / NWG;                // DMA pieces per wave per tensor per tile
   constexpr int DS = D / 16;
   constexpr int DT = D / 32;
   constexpr int N1 = 2 * DS;                       // QK^T MFMAs per tile
@@ -165,18 +171,21 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #define KT(i) (QKSPLIT ? (i) / DS : (i) & 1)
 #define KS(i) (QKSPLIT ? (i) % DS : (i) >> 1)
   constexpr bool PAIR = CAUSAL && (VF & VF_PAIR);
-  static_assert(PPW >= 1 && PPW * NW == PIECES, "tile does not split into whole DMA pieces per wave");
+  static_assert(PPW >= 1 && PPW * NWG == PIECES, "tile does not split into whole DMA pieces per wave");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  char* const kl = smem;                           // K buffers 0,1
-  char* const vl = smem + 2 * TILE_BYTES;          // V buffers 0,1
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = KSPLIT ? wave_id / NWG : 0;      // key-tile group of this wave (KSPLIT), its own four tile buffers
+  char* const gsm = smem + grp * 4 * TILE_BYTES;
+  char* const kl = gsm;                            // K buffers 0,1
+  char* const vl = gsm + 2 * TILE_BYTES;           // V buffers 0,1
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)gsm;
 
   unsigned long long t_start = 0, t_pro = 0, t_loop = 0, rt_start = 0;
   if (p.trace) { rt_start = __builtin_amdgcn_s_memrealtime(); t_start = __builtin_amdgcn_s_memtime(); }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = KSPLIT ? wave_id % NWG : wave_id;   // index inside the query block: rows, DMA pieces, epilogue slice
 #ifndef TFA_IL_WPERM
 #define TFA_IL_WPERM 0
 #endif
@@ -208,8 +217,20 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const T* vbase = reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h;
   // Q/O: one descriptor per query block (rsrc_at, once per pass).  K/V: one per slice, or — VF_IL_WINDOWED — one per tile.
   constexpr bool WIN = (VF & VF_IL_WINDOWED) != 0;
-  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, WIN ? 0u : (unsigned)p.k_bytes, 0x00020000);
-  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, WIN ? 0u : (unsigned)p.v_bytes, 0x00020000);
+  // KSPLIT: group g sees the key sequence through a strided view — its tile j is tile 2j+g of the head — with nk_eff keys
+  int nk_eff = p.Nk;
+  unsigned long long k_bytes = p.k_bytes, v_bytes = p.v_bytes;
+  if (KSPLIT) {
+    const int ntg = (p.Nk + BN - 1) / BN, cg = (ntg - grp + 1) / 2, rem = p.Nk - (ntg - 1) * BN;
+    nk_eff = (((ntg - 1) & 1) == grp) ? (cg - 1) * BN + rem : cg * BN;
+    const unsigned long long ko = (unsigned long long)grp * BN * p.ks_n * 2, vo = (unsigned long long)grp * BN * p.vs_n * 2;
+    kbase += grp * BN * p.ks_n;
+    vbase += grp * BN * p.vs_n;
+    k_bytes = k_bytes > ko ? k_bytes - ko : 0;
+    v_bytes = v_bytes > vo ? v_bytes - vo : 0;
+  }
+  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, WIN ? 0u : (unsigned)k_bytes, 0x00020000);
+  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, WIN ? 0u : (unsigned)v_bytes, 0x00020000);
 
   int k_src[PPW], v_src[PPW];
 #pragma unroll
@@ -229,15 +250,15 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       v_src[i] = (dt * 4 + pcs) * 8 < p.dv ? key * (int)p.vs_n * 2 + ((dt * 4 + pcs) << 4) : (int)TFA_OOB;
     }
   }
-  const int k_tile_stride = BN * (int)p.ks_n * 2;
-  const int v_tile_stride = BN * (int)p.vs_n * 2;
+  const int k_tile_stride = (KSPLIT ? 2 : 1) * BN * (int)p.ks_n * 2;
+  const int v_tile_stride = (KSPLIT ? 2 : 1) * BN * (int)p.vs_n * 2;
 
   auto dma_k1 = [&](int t, int buf, int i) {
-    if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(kbase, p.k_bytes, (unsigned long long)t * (unsigned)k_tile_stride), lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i]);
+    if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(kbase, k_bytes, (unsigned long long)t * (unsigned)k_tile_stride), lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i]);
     else lds_dma16_m0(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
   };
   auto dma_v1 = [&](int t, int buf, int i) {
-    if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(vbase, p.v_bytes, (unsigned long long)t * (unsigned)v_tile_stride), lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i]);
+    if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(vbase, v_bytes, (unsigned long long)t * (unsigned)v_tile_stride), lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i]);
     else lds_dma16_m0(v_rs, lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i] + t * v_tile_stride);
   };
   auto dma_k = [&](int t, int buf) {
@@ -274,7 +295,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   // requests for the start of query block mbx: K(0), V(0), K(1) by LDS-DMA and this lane's Q fragments
   auto issue_prologue = [&](int mbx, bool with_dma) {
     const int q0x = mbx * BM;
-    int kve = p.Nk;
+    int kve = nk_eff;
     if (CAUSAL) {
       const int lim = q0x + BM + shift;
       kve = lim < kve ? lim : kve;
@@ -300,17 +321,19 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     const int mb = block_of(pass);
     if (p.trace && pass == 1 && tr_pass == 1) t_start = __builtin_amdgcn_s_memtime();
     const int q0 = mb * BM;
-    int kv_end = p.Nk;
+    int kv_end = nk_eff;
     if (CAUSAL) {
       const int lim = q0 + BM + shift;
       kv_end = lim < kv_end ? lim : kv_end;
     }
-    const int nt = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+    const int nt_own = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+    // iterations of the WORKGROUP (barriers, DMA): KSPLIT: group 0's count — group 1 may have one tile less (nact below)
+    const int nt = KSPLIT ? ((p.Nk + BN - 1) / BN + 1) / 2 : nt_own;
     nt_total += nt;
 
     const int wave_row0 = q0 + wrow * 32;
     const int my_row = wave_row0 + qi;
-    const int wave_last_tile = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (nt - 1);
+    const int wave_last_tile = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (nt_own - 1);
 
     float l4[4] = {0.f, 0.f, 0.f, 0.f};              // row sum of P, four interleaved partial sums carried across the tiles
 
@@ -332,12 +355,12 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     };
     auto needs_mask = [&](int t) -> bool {
       const int key0 = t * BN;
-      bool nm = (key0 + BN > p.Nk);
+      bool nm = (key0 + BN > nk_eff);
       if (CAUSAL) nm = nm || (key0 + BN - 1 > wave_row0 + shift);
       return nm;
     };
     auto apply_mask = [&](int t, f32x16 (&s)[2]) {
-      int lim = p.Nk - 1;
+      int lim = nk_eff - 1;
       if (CAUSAL) { const int c = my_row + shift; lim = c < lim ? c : lim; }
       lim -= t * BN + 4 * hi;
 #pragma unroll
@@ -432,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     // first tile of this wave that needs masking (causal diagonal or ragged tail); nact if none
     int fm = nact;
     {
-      const int ragged = (p.Nk % BN) ? (p.Nk / BN) : nact;
+      const int ragged = (nk_eff % BN) ? (nk_eff / BN) : nact;
       fm = ragged < fm ? ragged : fm;
       if (CAUSAL) {
         const int c = wave_row0 + shift + 1;               // keys 0..c-1 are visible to every row of the wave
@@ -639,9 +662,51 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     // and Q now, so that their latency hides behind the normalisation and the stores below
     if (PREF && pass + 1 < npass) issue_prologue(block_of(pass + 1), true);
     if (SEAM) { seam_in = seam; if (seam) issue_prologue(block_of(pass + 1), false); }   // Q only: K(0), K(1), V(0) are on chip
-    const float l_tot = pair_sum((l4[0] + l4[1]) + (l4[2] + l4[3]));
+    float l_tot = pair_sum((l4[0] + l4[1]) + (l4[2] + l4[3]));
+    float w0 = 1.f, w1 = 0.f;                          // KSPLIT: weights of this group's and the other group's partial result
+    const char* const dump = smem + 4 * TILE_BYTES;    // KSPLIT: group 1's (now idle) tile buffers carry its O to group 0
+    if constexpr (KSPLIT) {
+      // the two groups hold partial results over disjoint key sets: group 1 writes (m, l, O) — lane-private data, no
+      // transposition — and leaves; group 0 merges by the split-KV rule (tfa_merge.hip) while it reads its own O out
+      float* const ml = reinterpret_cast<float*>(smem + wave * (32 * D * 2)) + lane * 2;   // (in group 0's idle buffers)
+      if (grp == 1) {
+        ml[0] = mref; ml[1] = l_tot;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          float o[16];
+          if (d == 0) o_read<0>(o, 1.f); else if (d == 1) o_read<1>(o, 1.f); else if (d == 2) o_read<2>(o, 1.f); else o_read<3>(o, 1.f);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v4 = {o[4 * g + 0], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(const_cast<char*>(dump) + ((((wave * DT + d) << 2) + g) << 10) + lane * 16) = v4;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (grp == 1) return;
+      const float m1 = ml[0], l1 = ml[1];
+      const float m = fmaxf(mref, m1);
+      w0 = (mref == -INFINITY) ? 0.f : fast_exp2(mref - m);
+      w1 = (m1 == -INFINITY) ? 0.f : fast_exp2(m1 - m);
+      l_tot = w0 * l_tot + w1 * l1;
+      mref = m;
+    }
     const bool empty = !(l_tot > 0.f);
     const float inv = empty ? 1.f : 1.f / l_tot;
+    // O[d tile d][0..15] of this lane, normalised (KSPLIT: merged with the other group's)
+    auto o_get = [&](int d, float (&o)[16]) {
+      const float f0 = inv * w0;
+      if (d == 0) o_read<0>(o, f0); else if (d == 1) o_read<1>(o, f0); else if (d == 2) o_read<2>(o, f0); else o_read<3>(o, f0);
+      if constexpr (KSPLIT) {
+        const float f1 = inv * w1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(dump + ((((wave * DT + d) << 2) + g) << 10) + lane * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[4 * g + e] = fmaf(f1, x[e], o[4 * g + e]);
+        }
+      }
+    };
     if (p.lse != nullptr && hi == 0 && my_row < p.Nq) {
       const float lse = empty ? INFINITY : (mref + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
       p.lse[(long long)bh * p.Nq + my_row] = lse;
@@ -653,7 +718,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         float o[16];
-        if (d == 0) o_read<0>(o, inv); else if (d == 1) o_read<1>(o, inv); else if (d == 2) o_read<2>(o, inv); else o_read<3>(o, inv);
+        o_get(d, o);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4 v4 = {o[4 * g + 0], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
@@ -680,7 +745,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         float o[16];
-        if (d == 0) o_read<0>(o, inv); else if (d == 1) o_read<1>(o, inv); else if (d == 2) o_read<2>(o, inv); else o_read<3>(o, inv);
+        o_get(d, o);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           t4 v4 = {(T)o[4 * g + 0], (T)o[4 * g + 1], (T)o[4 * g + 2], (T)o[4 * g + 3]};
@@ -715,7 +780,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         float o[16];
-        if (d == 0) o_read<0>(o, inv); else if (d == 1) o_read<1>(o, inv); else if (d == 2) o_read<2>(o, inv); else o_read<3>(o, inv);
+        o_get(d, o);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           t4 v4 = {(T)o[4 * g + 0], (T)o[4 * g + 1], (T)o[4 * g + 2], (T)o[4 * g + 3]};

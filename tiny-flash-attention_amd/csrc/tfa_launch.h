@@ -1,6 +1,6 @@
 // tfa_launch.h — host-side dispatch table shared by the per-(dtype, head-dim) instantiation units.
 #pragma once
-// The product library dispatches four kernels only (kDefaultVariant, kSmallGridVariant, kSplitVariant below); every
+// The product library dispatches six kernels only (kDefaultVariant, kSmallGridVariant, kKSplitVariant, kSplitVariant and the two x4 ones below); every
 // other entry of kVariants is a measured dead end or an A/B arm kept for the record and is compiled only with
 // -DTFA_EXPERIMENTAL (make EXPERIMENTAL=1).  Without the flag those variant numbers are rejected (TFA_ERR_VARIANT).
 #include <hip/hip_runtime.h>
@@ -62,6 +62,7 @@ static const Variant kVariants[] = {
     {"il-x4-pair-epi (issue-interleaved, 4 waves x 64 rows: one wave per SIMD, O and Q in AGPRs, K ring of three LDS buffers)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR | VF_X4_EPI, 2},
     {"x4-d256-pair (the x4 kernel with ONE 32-row block per wave: head dims 136..256, 128-row workgroups, O stored directly)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR, 1},
     {"il8-pair-dmaspread-epi-seam (variant 30 + the heavy pass's last tiles stream the light pass's K(0), K(1), V(0); Q before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_SEAM, 1},
+    {"il8-ksplit-epi (small non-causal grids: 8 waves on one 128-row block, waves 0-3 take the even KV tiles and waves 4-7 the odd ones, merged through LDS)", 8, VF_DMA | VF_IL | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
@@ -69,6 +70,7 @@ constexpr int kSmallGridVariant = 32;     // il4-pair-epi (128-row query blocks,
 constexpr int kX4Variant = 33;            // il-x4-pair-epi
 constexpr int kX4D256Variant = 34;        // x4-d256-pair: the only kernel for head dims above 128
 constexpr int kSeamVariant = 35;          // il8-pair-dmaspread-epi-seam
+constexpr int kKSplitVariant = 36;        // il8-ksplit-epi: grids of at most one 128-row block per CU, non-causal
 constexpr int kSplitVariant = 17;         // dma4-pair-2buf: the kernel whose grid can carry key chunks (tfa_fwd_splitkv)
 
 struct LaunchGeom {
@@ -84,7 +86,8 @@ static inline bool variant_built(int variant) {
 #if defined(TFA_EXPERIMENTAL)
   return true;
 #else
-  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant || variant == kX4Variant || variant == kX4D256Variant;
+  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant || variant == kX4Variant || variant == kX4D256Variant ||
+         variant == kKSplitVariant;
 #endif
 }
 
@@ -134,7 +137,11 @@ static inline bool windowed_slices(int variant) {
   return variant == kDefaultVariant || variant == kSmallGridVariant;   // the dispatched il kernels have a windowed instantiation
 }
 
-static inline int block_m_of(int variant) { return kVariants[variant].nw * 32 * kVariants[variant].rb; }
+static inline int block_m_of(int variant) {
+  const int rows = kVariants[variant].nw * 32 * kVariants[variant].rb;
+  return (kVariants[variant].vf & VF_IL_KSPLIT) ? rows / 2 : rows;   // two groups of waves share one query block
+}
+static inline bool non_causal_only(int variant) { return (kVariants[variant].vf & VF_IL_KSPLIT) != 0; }
 static inline bool uses_dma(int variant) { return (kVariants[variant].vf & VF_DMA) != 0; }
 static inline bool pairs_causal(int variant) { return (kVariants[variant].vf & VF_PAIR) != 0; }
 

@@ -9,7 +9,8 @@ CFG = {"cfg2": (4, 8, 1024, 64, torch.float16, False), "cfg3": (4, 32, 4096, 128
        "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg4c": (1, 16, 16384, 128, torch.bfloat16, True), "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),
        "d64": (4, 32, 4096, 64, torch.float16, False), "d64c": (4, 32, 4096, 64, torch.float16, True), "n2k": (8, 32, 2048, 128, torch.bfloat16, True),
        "n1k": (16, 32, 1024, 128, torch.bfloat16, True), "cfg3h16": (4, 16, 4096, 128, torch.bfloat16, True),
-       "n8k": (2, 32, 8192, 128, torch.bfloat16, True)}
+       "n8k": (2, 32, 8192, 128, torch.bfloat16, True), "cfg2b": (4, 8, 1024, 128, torch.bfloat16, False),
+       "s2k": (1, 16, 2048, 128, torch.bfloat16, False), "s512": (8, 8, 512, 64, torch.float16, False), "s4k": (1, 8, 4096, 128, torch.bfloat16, False)}
 ap = argparse.ArgumentParser()
 ap.add_argument("--variants", default="30,33")
 ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4")
