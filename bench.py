@@ -37,6 +37,7 @@ duration measured with HIP events on the launch stream over the same timed regio
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import math
 import os
@@ -276,6 +277,12 @@ def main():
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
+    # (the K launches are enqueued ~50x faster than they execute; a host stall longer than that head start opens a gap in
+    #  the stream and lands in `value` — seen once this round: 962 TF with every kernel at its usual 0.525 ms.  The garbage
+    #  collector is the one avoidable source; one replay of a HIP graph holding the K launches was tried and is 2.5 % SLOWER
+    #  than the loop: the runtime leaves a gap between graph kernel nodes.)
+    gc_was = gc.isenabled()
+    gc.disable()
     t0 = time.perf_counter()
     e0.record(stream)
     for _ in range(args.steps):
@@ -288,6 +295,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
     ev_ms = e0.elapsed_time(e1) / args.steps
 
     if dist is not None:

@@ -174,7 +174,7 @@ def tiled_emulation(q, k, v, is_causal, softmax_scale, block_n=64, p_dtype=None,
 
 
 def tiled_emulation_lazy(q, k, v, is_causal, softmax_scale, block_n=64, group=32, thresh=8.0, p_dtype=None,
-                         return_lse=False):
+                         return_lse=False, key_pos=None, nk_total=None):
     """The same tile loop as ``tiled_emulation`` with the issue-interleaved kernel's max rule
     (tiny-flash-attention_amd/csrc/tfa_fwd_kernel_il.h): instead of the exact running max of
     main_torch_only.py:240-257 every row keeps a REFERENCE exponent ``ref`` (log2 domain).  A group of
@@ -182,7 +182,9 @@ def tiled_emulation_lazy(q, k, v, is_causal, softmax_scale, block_n=64, group=32
     ``ref`` by more than ``thresh`` (2^8): then every row of the group takes ref = max(ref, tile max) and
     O, l are multiplied by exp2(old - new).  P = exp2(s*scale*log2e - ref) <= 2^thresh, so nothing can
     overflow, and the final O = acc / l and LSE = (ref + log2 l) ln2 are unchanged mathematically; only the
-    rounding points of the 16-bit P move.  With thresh=0 and group=1 this is the exact-max rule again."""
+    rounding points of the 16-bit P move.  With thresh=0 and group=1 this is the exact-max rule again.
+    ``key_pos`` / ``nk_total``: the keys given are a SUBSET of a sequence of nk_total keys at these positions (the
+    key-split kernel's wave groups); the causal mask compares positions in the whole sequence."""
     B, H, Nq, D = q.shape
     _, Hk, Nk, _ = k.shape
     dt = q.dtype if p_dtype is None else p_dtype
@@ -198,13 +200,14 @@ def tiled_emulation_lazy(q, k, v, is_causal, softmax_scale, block_n=64, group=32
     acc = torch.zeros((B, H, Nq, D), dtype=torch.float32)
     l = torch.zeros((B, H, Nq, 1), dtype=torch.float32)
     ref = torch.full((B, H, Nq, 1), -1e30, dtype=torch.float32)
-    rows = torch.arange(Nq)[:, None] + (Nk - Nq)
+    rows = torch.arange(Nq)[:, None] + ((Nk if nk_total is None else nk_total) - Nq)
+    pos = torch.arange(Nk) if key_pos is None else key_pos
     for kv_start in range(0, Nk, block_n):
         k_tile = kf[:, :, kv_start:kv_start + block_n, :]
         v_tile = vf[:, :, kv_start:kv_start + block_n, :]
         s = torch.matmul(qf, k_tile.transpose(2, 3))
         if is_causal:
-            cols = kv_start + torch.arange(k_tile.shape[2])[None, :]
+            cols = pos[kv_start:kv_start + block_n][None, :]
             s = s.masked_fill(cols > rows, -math.inf)
         xm = s.max(dim=-1, keepdim=True).values * sc2                       # fp32 product, as the kernel
         over = xm > ref + thresh
@@ -227,11 +230,11 @@ def tiled_emulation_lazy(q, k, v, is_causal, softmax_scale, block_n=64, group=32
     return out
 
 
-def ksplit_emulation(q, k, v, softmax_scale, block_n=64, return_lse=False, **kw):
-    """Rounding points of the key-split kernel (VF_IL_KSPLIT in tiny-flash-attention_amd/csrc/tfa_fwd_kernel_il.h; non-causal):
-    two wave groups run ``tiled_emulation_lazy`` over the even and the odd ``block_n``-key tiles of the sequence and the two
-    partial results are combined by the split-KV rule (tiny_flash_attn.py:63-68 / README_zh.md:104-125 restated in
-    ``merge_partials``)."""
+def ksplit_emulation(q, k, v, is_causal, softmax_scale, block_n=64, return_lse=False, **kw):
+    """Rounding points of the key-split kernel (VF_IL_KSPLIT in tiny-flash-attention_amd/csrc/tfa_fwd_kernel_il.h):
+    two wave groups run ``tiled_emulation_lazy`` over the even and the odd ``block_n``-key tiles of the sequence (causal
+    mask against the positions in the whole sequence) and the two partial results are combined by the split-KV rule
+    (tiny_flash_attn.py:63-68 / README_zh.md:104-125 restated in ``merge_partials``)."""
     Nk = k.shape[2]
     nt = (Nk + block_n - 1) // block_n
     outs, lses = [], []
@@ -240,8 +243,8 @@ def ksplit_emulation(q, k, v, softmax_scale, block_n=64, return_lse=False, **kw)
         if not idx:
             continue
         idx = torch.cat(idx)
-        o, l = tiled_emulation_lazy(q, k.detach().cpu()[:, :, idx], v.detach().cpu()[:, :, idx], False, softmax_scale, block_n,
-                                    return_lse=True, **kw)
+        o, l = tiled_emulation_lazy(q, k.detach().cpu()[:, :, idx], v.detach().cpu()[:, :, idx], is_causal, softmax_scale, block_n,
+                                    return_lse=True, key_pos=idx, nk_total=Nk, **kw)
         outs.append(o)
         lses.append(l)
     out, lse = merge_partials(torch.stack(outs), torch.stack(lses))

@@ -58,9 +58,13 @@ def test_plan_geometry():
     _lib.set_variant(-1)  # automatic: headline shape -> issue-interleaved kernel, 256-row blocks paired, 2 K + 2 V buffers
     st, grid, block, lds = plan(_params(**big))   # + one 32-row epilogue slice per wave
     assert st == 0 and block == 512 and grid == 4 * 32 * 8 and lds == 4 * 64 * 128 * 2 + 8 * 32 * 128 * 2
-    # automatic, small grid (BASELINE config 2) -> 128-row blocks, two 4-wave workgroups per CU
+    # automatic, at most one 128-row block per CU (BASELINE config 2's shape, causal here) -> the key-split kernel: 8 waves per
+    # 128-row block, unpaired, two groups of four tile buffers
     st, grid, block, lds = plan(_params(B=4, H=8, Hk=8, Nq=1024, Nk=1024, D=64, dtype=_lib.TFA_F16))
-    assert st == 0 and block == 256 and grid == 4 * 8 * 4 and lds == 4 * 64 * 64 * 2
+    assert st == 0 and block == 512 and grid == 4 * 8 * 8 and lds == 8 * 64 * 64 * 2
+    # automatic, two 128-row blocks per CU -> 128-row blocks paired, two 4-wave workgroups per CU
+    st, grid, block, lds = plan(_params(B=4, H=16, Hk=16, Nq=1024, Nk=1024, D=64, dtype=_lib.TFA_F16))
+    assert st == 0 and block == 256 and grid == 4 * 16 * 4 and lds == 4 * 64 * 64 * 2
     if _lib.variant_available(1):   # A/B arms (make EXPERIMENTAL=1)
         _lib.set_variant(1)
         st, grid, block, lds = plan(_params(**big))
@@ -203,7 +207,7 @@ def test_variant_selection_is_introspectable_without_gpu():
     # big grids -> the 8-wave issue-interleaved kernel, small grids -> its 4-wave form (128-row blocks, 2 workgroups per CU);
     # non-causal grids of at most one 128-row block per CU with >= 16 KV tiles -> the key-split form (BASELINE config 2)
     big = _lib.variant_for(4, 32, 32, 4096, 4096, 128, True)
-    small = _lib.variant_for(4, 8, 8, 1024, 1024, 64, True, _lib.TFA_F16)
+    small = _lib.variant_for(4, 16, 16, 1024, 1024, 64, True, _lib.TFA_F16)
     cfg2 = _lib.variant_for(4, 8, 8, 1024, 1024, 64, False, _lib.TFA_F16)
     assert _lib.variant_name(big).startswith("il8-pair") and _lib.lazy_reference(big)
     assert _lib.variant_name(small).startswith("il4") and _lib.lazy_reference(small)

@@ -46,15 +46,13 @@ def tfa():
     _lib.set_variant(-1)
 
 
-KSPLIT = 36      # il8-ksplit-epi: non-causal only
+KSPLIT = 36      # il8-ksplit-epi
 
 
 def _need_variant(variant, causal=False):
     """The product build carries the dispatched kernels only; A/B arms need `make EXPERIMENTAL=1` (tfa_launch.h)."""
     from tiny_flash_attention_amd import _lib
 
-    if variant == KSPLIT and causal:
-        pytest.skip("the key-split kernel is non-causal only (TFA_ERR_VARIANT otherwise: test_ksplit_*)")
     if variant >= 0 and not _lib.variant_available(variant):
         pytest.skip(f"kernel variant {variant} is an A/B arm: not in the product build (make EXPERIMENTAL=1)")
 
@@ -68,7 +66,7 @@ def check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype, var=None):
         var = _lib.variant_for(q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3], causal)
     emulate = oracle.tiled_emulation_lazy if _lib.lazy_reference(var) else oracle.tiled_emulation
     if var == KSPLIT:                                   # two wave groups over the even / odd key tiles, merged
-        emu, lse_e = oracle.ksplit_emulation(q, k, v, sc, 64, return_lse=True)
+        emu, lse_e = oracle.ksplit_emulation(q, k, v, causal, sc, 64, return_lse=True)
     else:
         emu, lse_e = emulate(q, k, v, causal, sc, 64, return_lse=True)
     exact, lse_x = oracle.exact64(q, k, v, causal, sc, return_lse=True)
@@ -585,30 +583,45 @@ def test_windowed_instantiation_returns_the_same_bits(tfa, dev, variant, causal)
         _lib.set_variant(-1)
 
 
+@pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D", [
     (torch.float16, 4, 8, 8, 1024, 1024, 64),        # BASELINE config 2: 256 blocks of 128 rows = one per CU
-    (torch.bfloat16, 1, 8, 2, 512, 1000, 128),       # GQA; 16 tiles, the ragged last one (15) belongs to group 1
+    (torch.bfloat16, 1, 8, 2, 512, 1000, 128),       # GQA; 16 tiles, the ragged last one (15) belongs to group 1; Nq < Nk
     (torch.bfloat16, 2, 4, 4, 300, 961, 128),        # 16 tiles, the last holds ONE key
-    (torch.bfloat16, 1, 4, 4, 200, 1089, 128),       # 18 tiles, the ragged last one (17: one key) belongs to group 1 ... 1089 = 17*64 + 1
+    (torch.bfloat16, 1, 4, 4, 200, 1089, 128),       # 18 tiles, the last (17: one key) belongs to group 1
     (torch.float16, 1, 16, 16, 128, 320, 64),        # 5 tiles: group 0 has 3, group 1 has 2 (the workgroup iterates 3 times)
     (torch.bfloat16, 1, 2, 2, 77, 256, 96),          # padded head dim, ragged rows
     (torch.float16, 1, 2, 2, 100, 40, 64),           # ONE tile: group 1 has nothing to do and contributes weight 0
+    (torch.bfloat16, 1, 2, 2, 700, 300, 128),        # Nq > Nk: causal rows 0..399 see no key at all (O = 0, LSE = +inf)
+    (torch.bfloat16, 1, 2, 2, 1500, 1500, 128),      # 12 query blocks, the diagonal in every tile parity
 ])
-def test_ksplit_small_noncausal_grids(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D):
-    """The key-split kernel (8 waves on one 128-row block, even / odd KV tiles per wave group, merged through LDS), forced
-    onto small non-causal problems; the dispatcher picks it by itself for grids of at most one 128-row block per CU with at
-    least 16 KV tiles.  Same tolerances as every other kernel (check(), with the split's own rounding points)."""
+def test_ksplit_small_grids(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal):
+    """The key-split kernel (8 waves on one 128-row block, even / odd KV tiles per wave group, merged through LDS) forced
+    onto small problems, causal (bottom-right mask against the positions in the whole sequence) and not.  Same tolerances
+    as every other kernel (check(), against the split's own rounding points: oracle.ksplit_emulation)."""
     from tiny_flash_attention_amd import _lib
 
-    assert (_lib.variant_for(B, H, Hk, Nq, Nk, D, False) == KSPLIT) == (Nk >= 1024)
-    assert _lib.variant_for(B, H, Hk, Nq, Nk, D, True) != KSPLIT
     _lib.set_variant(KSPLIT)
     try:
-        run_case(tfa, oracle, dev, dtype, B, H, Nq, D, False, Hk=Hk, Nk=Nk, seed=41)
-        with pytest.raises(_lib.TfaError):               # forced onto a causal problem: refused, not silently wrong
-            run_case(tfa, oracle, dev, dtype, 1, 1, 128, D, True, seed=1)
+        run_case(tfa, oracle, dev, dtype, B, H, Nq, D, causal, Hk=Hk, Nk=Nk, seed=41)
     finally:
         _lib.set_variant(-1)
+
+
+def test_ksplit_dispatch_rule():
+    """Grids of at most one 128-row block per CU: non-causal from 16 KV tiles on, causal from 8.  Non-causal grids with at
+    least one 256-row block per CU take the 8-wave kernel.  (No GPU needed; kept with the GPU parity tests it belongs to.)"""
+    from tiny_flash_attention_amd import _lib
+
+    name = lambda *a: _lib.variant_name(_lib.variant_for(*a)).split(" ")[0]
+    assert name(4, 8, 8, 1024, 1024, 64, False) == "il8-ksplit-epi"          # BASELINE config 2
+    assert name(1, 8, 8, 4096, 4096, 128, False) == "il8-ksplit-epi"
+    assert name(1, 8, 8, 4096, 4096, 128, True) == "il8-ksplit-epi"
+    assert name(1, 64, 64, 512, 512, 128, True) == "il8-ksplit-epi"
+    assert name(4, 8, 8, 512, 512, 64, False) == "il4-pair-epi"              # 8 tiles, non-causal: the merge costs more than it returns
+    assert name(1, 16, 16, 4096, 4096, 128, True) == "il4-pair-epi"          # two 128-row blocks per CU
+    assert name(1, 16, 16, 4096, 4096, 128, False) == "il8-pair-dmaspread-epi"   # one 256-row block per CU, non-causal
+    assert name(4, 32, 32, 4096, 4096, 128, True) == "il8-pair-dmaspread-epi"    # the grid fills the chip
 
 
 def test_dropin_extension_module_attention_cutlass(tfa, oracle, dev):

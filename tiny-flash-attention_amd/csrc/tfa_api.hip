@@ -39,13 +39,23 @@ int pick_variant(const tfa_fwd_params* p) {
   // B4 H8 N1024 has only 128 blocks of 256 rows).
   // The issue-interleaved kernel (tfa_fwd_kernel_il.h) wins wherever the grid fills the chip (+5..11% at D=128).
   const long long blocks256 = (long long)p->B * p->H * ((p->Nq + 255) / 256);
+  const long long blocks128 = (long long)p->B * p->H * ((p->Nq + 127) / 128);
+  const int cus = num_cus();
+  const bool whole_seq = p->kv_offset == 0 && p->nk_total == 0;
+  // Grids of at most one 128-row block per CU: the 4-wave kernel would run one wave per SIMD (causal: paired, on half the CUs) —
+  // split the keys inside the workgroup instead (il8-ksplit: 8 waves on one block, unpaired).  Non-causal it pays from 16 KV
+  // tiles on (BASELINE config 2 +5 %, B1 H16 N2048 +9 %, B1 H8 N4096 +12 %; N=512 -4 %), causal always (B1 H8 N4096 +32 %,
+  // B1 H16 N2048 +32 %, B1 H64 N512 +32 %); with two blocks per CU it is mixed (-20 .. +10 %) and not used
+  // (profiles/r02_ksplit_ab.txt).
+  const auto small = [&](int64_t n, const int64_t* st, int es) { return ((n + 512) * st[2] + p->D) * es < (int64_t)0x7fffffff; };
+  const bool one_descriptor = small(p->Nq, p->q_stride, 2) && small(p->Nk, p->k_stride, 2) && small(p->Nk, p->v_stride, 2) &&
+                              small(p->Nq, p->o_stride, 4);   // (slices of 2 GiB and more: the windowed il4 / il8 instantiations)
+  if (whole_seq && one_descriptor && blocks128 <= cus && p->Nk >= (p->is_causal ? 512 : 1024)) return tfa::kKSplitVariant;
+  // non-causal, at least one 256-row block per CU: the 8-wave kernel already has two waves per SIMD everywhere
+  // (B1 H16 N4096: 1160 vs 1091 TF for il4, B1 H32 N2048: 1098 vs 1038)
+  if (!p->is_causal && blocks256 >= cus) return tfa::kDefaultVariant;
   // small grids: 128-row blocks, two 4-wave workgroups per CU, issue-interleaved, O through the idle tile buffers
   // (D=128: +8..15 % over the burst kernel on B1 H8 N2048 / B2 H16 N1024 / B1 H32 N4096; D=64, BASELINE config 2: +2 %)
-  // at most one 128-row block per CU, non-causal: the 4-wave kernel would run one wave per SIMD — split the keys inside the
-  // workgroup instead (8 waves, two per SIMD).  Pays from 16 KV tiles on: BASELINE config 2 (N=1024, D=64) +5 %, B1 H16 N2048
-  // D128 +9 %, B1 H8 N4096 +12 %; N=512 -4 % (profiles/r02_ksplit_ab.txt)
-  const long long blocks128 = (long long)p->B * p->H * ((p->Nq + 127) / 128);
-  if (!p->is_causal && blocks128 <= num_cus() && p->Nk >= 1024 && p->kv_offset == 0 && p->nk_total == 0) return tfa::kKSplitVariant;
   if (blocks256 < 512) return tfa::kSmallGridVariant;
   // (with O leaving through LDS the 8-wave il kernel also wins on short sequences: N=512..2048, causal or not, it beats
   //  the 4-wave one by 3-5 %, tests/tools/ab.py n512/n1k/n2k configs)
@@ -82,7 +92,6 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   if (!ablate && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
   if (p->D != 64 && p->D != 128 && (ablate || !tfa::supports_padded_d(variant))) return TFA_ERR_HEAD_DIM;   // (A/B arms: 64 / 128 only)
   if ((p->D > 128) != (variant == tfa::kX4D256Variant)) return TFA_ERR_HEAD_DIM;
-  if (!ablate && tfa::non_causal_only(variant) && p->is_causal) return TFA_ERR_VARIANT;
   const int esz = 2, osz = (p->out_dtype == TFA_F32) ? 4 : 2;
   const int64_t* st[4] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride};
   for (int t = 0; t < 4; ++t) {

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   constexpr bool KSPLIT = (VF & VF_IL_KSPLIT) != 0;
   constexpr int NWG = KSPLIT ? NW / 2 : NW;        // waves per query block (KSPLIT: per key-tile group)
   constexpr int BM = NWG * 32;
-  static_assert(!KSPLIT || (!CAUSAL && !(VF & VF_PAIR) && (VF & VF_IL_EPI_INPLACE) && !(VF & (VF_IL_SEAM | VF_IL_PREF | VF_IL_WINDOWED))), "KSPLIT: non-causal, in-place epilogue");
+  static_assert(!KSPLIT || (!(VF & VF_PAIR) && (VF & VF_IL_EPI_INPLACE) && !(VF & (VF_IL_SEAM | VF_IL_PREF | VF_IL_WINDOWED))), "KSPLIT: one pass per workgroup, in-place epilogue");
+  constexpr int KSTEP = KSPLIT ? 2 : 1;            // a wave's tile t is tile KSTEP*t + grp of the head
   constexpr int BN = 64;
   constexpr int CPR = D / 8;
   constexpr int TILE_BYTES = BN * D * 2;
@@ -217,12 +218,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const T* vbase = reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h;
   // Q/O: one descriptor per query block (rsrc_at, once per pass).  K/V: one per slice, or — VF_IL_WINDOWED — one per tile.
   constexpr bool WIN = (VF & VF_IL_WINDOWED) != 0;
-  // KSPLIT: group g sees the key sequence through a strided view — its tile j is tile 2j+g of the head — with nk_eff keys
-  int nk_eff = p.Nk;
+  // KSPLIT: group g sees the key sequence through a strided view — its tile j is tile 2j+g of the head
   unsigned long long k_bytes = p.k_bytes, v_bytes = p.v_bytes;
   if (KSPLIT) {
-    const int ntg = (p.Nk + BN - 1) / BN, cg = (ntg - grp + 1) / 2, rem = p.Nk - (ntg - 1) * BN;
-    nk_eff = (((ntg - 1) & 1) == grp) ? (cg - 1) * BN + rem : cg * BN;
     const unsigned long long ko = (unsigned long long)grp * BN * p.ks_n * 2, vo = (unsigned long long)grp * BN * p.vs_n * 2;
     kbase += grp * BN * p.ks_n;
     vbase += grp * BN * p.vs_n;
@@ -288,6 +286,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   static_assert(!(SEAM && (VF & VF_IL_EPI_INPLACE)), "the in-place epilogue would overwrite the streamed tiles");
   bool seam_in = false;                              // this pass's first tiles and Q were requested by the previous pass
   X8 qf[DS];
+  auto own_tiles = [&](int ntg) -> int { return KSPLIT ? (ntg - grp + 1) >> 1 : ntg; };   // this wave's share of ntg tiles of the head
+  auto key0_of = [&](int t) -> int { return (KSTEP * t + grp) * BN; };                        // first key of the wave's tile t
   auto block_of = [&](int pass) -> int {
     if (PAIR) return pass == 0 ? (p.nmb - 1 - wi) : wi;
     return CAUSAL ? (p.nmb - 1 - wi) : wi;
@@ -295,12 +295,12 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   // requests for the start of query block mbx: K(0), V(0), K(1) by LDS-DMA and this lane's Q fragments
   auto issue_prologue = [&](int mbx, bool with_dma) {
     const int q0x = mbx * BM;
-    int kve = nk_eff;
+    int kve = p.Nk;
     if (CAUSAL) {
       const int lim = q0x + BM + shift;
       kve = lim < kve ? lim : kve;
     }
-    const int ntx = kve > 0 ? (kve + BN - 1) / BN : 0;
+    const int ntx = own_tiles(kve > 0 ? (kve + BN - 1) / BN : 0);
     if (with_dma && ntx > 0) dma_k(0, 0);
     if (with_dma && ntx > 0) dma_v(0, 0);
     if (with_dma && ntx > 1) dma_k(1, 1);
@@ -321,19 +321,21 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     const int mb = block_of(pass);
     if (p.trace && pass == 1 && tr_pass == 1) t_start = __builtin_amdgcn_s_memtime();
     const int q0 = mb * BM;
-    int kv_end = nk_eff;
+    int kv_end = p.Nk;
     if (CAUSAL) {
       const int lim = q0 + BM + shift;
       kv_end = lim < kv_end ? lim : kv_end;
     }
-    const int nt_own = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+    const int ntg = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;   // tiles of the head this block visits
+    const int nt_own = own_tiles(ntg);
     // iterations of the WORKGROUP (barriers, DMA): KSPLIT: group 0's count — group 1 may have one tile less (nact below)
-    const int nt = KSPLIT ? ((p.Nk + BN - 1) / BN + 1) / 2 : nt_own;
+    const int nt = KSPLIT ? (ntg + 1) >> 1 : ntg;
     nt_total += nt;
 
     const int wave_row0 = q0 + wrow * 32;
     const int my_row = wave_row0 + qi;
-    const int wave_last_tile = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (nt_own - 1);
+    const int last_g = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (ntg - 1);   // last tile of the head the wave's rows see
+    const int wave_last_tile = KSPLIT ? (last_g >= grp ? (last_g - grp) >> 1 : -1) : last_g;
 
     float l4[4] = {0.f, 0.f, 0.f, 0.f};              // row sum of P, four interleaved partial sums carried across the tiles
 
@@ -354,15 +356,15 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       return __builtin_bit_cast(X8, __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     auto needs_mask = [&](int t) -> bool {
-      const int key0 = t * BN;
-      bool nm = (key0 + BN > nk_eff);
+      const int key0 = key0_of(t);
+      bool nm = (key0 + BN > p.Nk);
       if (CAUSAL) nm = nm || (key0 + BN - 1 > wave_row0 + shift);
       return nm;
     };
     auto apply_mask = [&](int t, f32x16 (&s)[2]) {
-      int lim = nk_eff - 1;
+      int lim = p.Nk - 1;
       if (CAUSAL) { const int c = my_row + shift; lim = c < lim ? c : lim; }
-      lim -= t * BN + 4 * hi;
+      lim -= key0_of(t) + 4 * hi;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -451,17 +453,19 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     if (p.trace && pass == tr_pass) t_pro = __builtin_amdgcn_s_memtime();
 
     // tiles this wave computes: 0 .. nact-1 (causal: the waves of a block stop at different tiles)
-    const int nact = (wave_last_tile + 1 < nt) ? (wave_last_tile + 1) : nt;
+    const int nact = (wave_last_tile + 1 < nt_own) ? (wave_last_tile + 1) : nt_own;
     // first tile of this wave that needs masking (causal diagonal or ragged tail); nact if none
     int fm = nact;
     {
-      const int ragged = (nk_eff % BN) ? (nk_eff / BN) : nact;
-      fm = ragged < fm ? ragged : fm;
+      int first_g = 0x3fffffff;                            // first tile OF THE HEAD that needs a mask for this wave
+      if (p.Nk % BN) first_g = p.Nk / BN;
       if (CAUSAL) {
         const int c = wave_row0 + shift + 1;               // keys 0..c-1 are visible to every row of the wave
         const int full = c > 0 ? c / BN : 0;               // tiles 0..full-1 need no mask
-        fm = full < fm ? full : fm;
+        first_g = full < first_g ? full : first_g;
       }
+      const int first = KSPLIT ? (first_g <= grp ? 0 : (first_g - grp + 1) >> 1) : first_g;   // ... in the wave's own tile numbering
+      fm = first < fm ? first : fm;
     }
 
     f32x16 sA[2], sB[2];

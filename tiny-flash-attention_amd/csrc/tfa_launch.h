@@ -62,7 +62,7 @@ static const Variant kVariants[] = {
     {"il-x4-pair-epi (issue-interleaved, 4 waves x 64 rows: one wave per SIMD, O and Q in AGPRs, K ring of three LDS buffers)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR | VF_X4_EPI, 2},
     {"x4-d256-pair (the x4 kernel with ONE 32-row block per wave: head dims 136..256, 128-row workgroups, O stored directly)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR, 1},
     {"il8-pair-dmaspread-epi-seam (variant 30 + the heavy pass's last tiles stream the light pass's K(0), K(1), V(0); Q before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_SEAM, 1},
-    {"il8-ksplit-epi (small non-causal grids: 8 waves on one 128-row block, waves 0-3 take the even KV tiles and waves 4-7 the odd ones, merged through LDS)", 8, VF_DMA | VF_IL | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
+    {"il8-ksplit-epi (small grids: 8 waves on one 128-row block, waves 0-3 take the even KV tiles and waves 4-7 the odd ones, merged through LDS)", 8, VF_DMA | VF_IL | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
@@ -141,7 +141,6 @@ static inline int block_m_of(int variant) {
   const int rows = kVariants[variant].nw * 32 * kVariants[variant].rb;
   return (kVariants[variant].vf & VF_IL_KSPLIT) ? rows / 2 : rows;   // two groups of waves share one query block
 }
-static inline bool non_causal_only(int variant) { return (kVariants[variant].vf & VF_IL_KSPLIT) != 0; }
 static inline bool uses_dma(int variant) { return (kVariants[variant].vf & VF_DMA) != 0; }
 static inline bool pairs_causal(int variant) { return (kVariants[variant].vf & VF_PAIR) != 0; }
 
