@@ -20,6 +20,12 @@
 //   The loop is unrolled by two so buffer addresses are immediates and S(j)/S(j+1) swap without copies.
 //   Tiles that need masking (causal diagonal, ragged tail) run the same body with the mask applied
 //   between the two parts (template flag, real branch: never if-converted into the steady state).
+//
+// Three forms are dispatched (tfa_api.hip:pick_variant): 8 waves x 32 rows = 256-row blocks, one workgroup per CU (il8, the
+// default); 4 waves = 128-row blocks, two workgroups per CU (il4, medium grids); and the KEY-SPLIT form for grids of at most
+// one 128-row block per CU (VF_IL_KSPLIT: 8 waves on one 128-row block, the two groups of four waves take the even / odd
+// KV tiles and merge through LDS).  il8 and il4 also exist with per-tile buffer descriptors for head slices of 2 GiB and
+// more (VF_IL_WINDOWED).
 #pragma once
 #include <type_traits>
 #include "tfa_fwd_kernel_dma.h"
