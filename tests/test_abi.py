@@ -88,7 +88,7 @@ def test_product_build_rejects_ab_arms():
     # the product library carries the dispatched kernels only (tfa_launch.h); the other table entries answer TFA_ERR_VARIANT
     L = _lib.lib()
     avail = [v for v in range(_lib.num_variants()) if _lib.variant_available(v)]
-    for v in (17, 30, 32, 33, 34, 36):
+    for v in (17, 30, 32, 33, 34, 36, 37):
         assert v in avail
     for v in range(_lib.num_variants()):
         if v not in avail:

@@ -47,6 +47,7 @@ def tfa():
 
 
 KSPLIT = 36      # il8-ksplit-epi
+KSPLIT_PAIR = 37 # il8-ksplit-pair-epi (causal blocks paired)
 
 
 def _need_variant(variant, causal=False):
@@ -65,7 +66,7 @@ def check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype, var=None):
     if var is None:
         var = _lib.variant_for(q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3], causal)
     emulate = oracle.tiled_emulation_lazy if _lib.lazy_reference(var) else oracle.tiled_emulation
-    if var == KSPLIT:                                   # two wave groups over the even / odd key tiles, merged
+    if var in (KSPLIT, KSPLIT_PAIR):                    # two wave groups over the even / odd key tiles, merged
         emu, lse_e = oracle.ksplit_emulation(q, k, v, causal, sc, 64, return_lse=True)
     else:
         emu, lse_e = emulate(q, k, v, causal, sc, 64, return_lse=True)
@@ -123,7 +124,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29, 30, 31, 32, 33, 35, 36])
+@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29, 30, 31, 32, 33, 35, 36, 37])
 @pytest.mark.parametrize("dtype,B,H,N,D,causal", SHAPES)
 def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
     from tiny_flash_attention_amd import _lib
@@ -136,7 +137,7 @@ def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causa
         _lib.set_variant(-1)
 
 
-@pytest.mark.parametrize("variant", [-1, 17, 30, 31, 33, 35, 36])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
+@pytest.mark.parametrize("variant", [-1, 17, 30, 31, 33, 35, 36, 37])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
 @pytest.mark.parametrize("Nq,Nk,causal", [(128, 384, True), (384, 128, True), (100, 333, False), (1, 1000, True), (257, 64, False),
                                           (700, 1500, True), (1111, 1111, False)])
 def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
@@ -583,6 +584,7 @@ def test_windowed_instantiation_returns_the_same_bits(tfa, dev, variant, causal)
         _lib.set_variant(-1)
 
 
+@pytest.mark.parametrize("variant", [KSPLIT, KSPLIT_PAIR])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D", [
     (torch.float16, 4, 8, 8, 1024, 1024, 64),        # BASELINE config 2: 256 blocks of 128 rows = one per CU
@@ -595,13 +597,15 @@ def test_windowed_instantiation_returns_the_same_bits(tfa, dev, variant, causal)
     (torch.bfloat16, 1, 2, 2, 700, 300, 128),        # Nq > Nk: causal rows 0..399 see no key at all (O = 0, LSE = +inf)
     (torch.bfloat16, 1, 2, 2, 1500, 1500, 128),      # 12 query blocks, the diagonal in every tile parity
 ])
-def test_ksplit_small_grids(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal):
+def test_ksplit_small_grids(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, variant):
     """The key-split kernel (8 waves on one 128-row block, even / odd KV tiles per wave group, merged through LDS) forced
     onto small problems, causal (bottom-right mask against the positions in the whole sequence) and not.  Same tolerances
     as every other kernel (check(), against the split's own rounding points: oracle.ksplit_emulation)."""
     from tiny_flash_attention_amd import _lib
 
-    _lib.set_variant(KSPLIT)
+    if variant == KSPLIT_PAIR and not causal:
+        pytest.skip("pairing only exists for causal problems (the non-causal instantiation is the unpaired kernel's)")
+    _lib.set_variant(variant)
     try:
         run_case(tfa, oracle, dev, dtype, B, H, Nq, D, causal, Hk=Hk, Nk=Nk, seed=41)
     finally:
@@ -619,7 +623,8 @@ def test_ksplit_dispatch_rule():
     assert name(1, 8, 8, 4096, 4096, 128, True) == "il8-ksplit-epi"
     assert name(1, 64, 64, 512, 512, 128, True) == "il8-ksplit-epi"
     assert name(4, 8, 8, 512, 512, 64, False) == "il4-pair-epi"              # 8 tiles, non-causal: the merge costs more than it returns
-    assert name(1, 16, 16, 4096, 4096, 128, True) == "il4-pair-epi"          # two 128-row blocks per CU
+    assert name(1, 16, 16, 4096, 4096, 128, True) == "il8-ksplit-pair-epi"   # two 128-row blocks per CU, long sequence: paired key-split
+    assert name(1, 32, 32, 2048, 2048, 128, True) == "il4-pair-epi"          # two 128-row blocks per CU, short sequence
     assert name(1, 16, 16, 4096, 4096, 128, False) == "il8-pair-dmaspread-epi"   # one 256-row block per CU, non-causal
     assert name(4, 32, 32, 4096, 4096, 128, True) == "il8-pair-dmaspread-epi"    # the grid fills the chip
 

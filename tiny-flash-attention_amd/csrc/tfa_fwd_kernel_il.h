@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   constexpr bool KSPLIT = (VF & VF_IL_KSPLIT) != 0;
   constexpr int NWG = KSPLIT ? NW / 2 : NW;        // waves per query block (KSPLIT: per key-tile group)
   constexpr int BM = NWG * 32;
-  static_assert(!KSPLIT || (!(VF & VF_PAIR) && (VF & VF_IL_EPI_INPLACE) && !(VF & (VF_IL_SEAM | VF_IL_PREF | VF_IL_WINDOWED))), "KSPLIT: one pass per workgroup, in-place epilogue");
+  static_assert(!KSPLIT || ((VF & VF_IL_EPI_INPLACE) && !(VF & (VF_IL_SEAM | VF_IL_PREF | VF_IL_WINDOWED))), "KSPLIT: in-place epilogue");
   constexpr int KSTEP = KSPLIT ? 2 : 1;            // a wave's tile t is tile KSTEP*t + grp of the head
   constexpr int BN = 64;
   constexpr int CPR = D / 8;
@@ -693,7 +693,13 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (grp == 1) return;
+      if (grp == 1) {
+        if (pass + 1 >= npass) return;
+        // paired causal blocks: group 0 still reads this group's buffers (the dump) and writes its own (epilogue slices);
+        // the next pass's first DMA pieces wait behind the barrier group 0 ends its epilogue with
+        asm volatile("s_barrier" ::: "memory");
+        continue;
+      }
       const float m1 = ml[0], l1 = ml[1];
       const float m = fmaxf(mref, m1);
       w0 = (mref == -INFINITY) ? 0.f : fast_exp2(mref - m);
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       }
       if (INPLACE) {
         // the next pass's first DMA pieces land in these buffers: every wave must have read its rows back
-        if (pass + 1 < npass) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!KSPLIT && pass + 1 < npass) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (KSPLIT: below, every output type)
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by this wave's next epilogue only
       }
@@ -798,6 +804,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         }
       }
     }
+    // KSPLIT, another pass to come: group 0 has read group 1's dump and its own epilogue slices — both live in tile buffers the
+    // next pass's first DMA pieces overwrite (group 1 waits at the matching barrier right behind the merge)
+    if (KSPLIT && pass + 1 < npass) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
   if (p.trace) {

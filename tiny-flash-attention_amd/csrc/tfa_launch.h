@@ -63,6 +63,7 @@ static const Variant kVariants[] = {
     {"x4-d256-pair (the x4 kernel with ONE 32-row block per wave: head dims 136..256, 128-row workgroups, O stored directly)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR, 1},
     {"il8-pair-dmaspread-epi-seam (variant 30 + the heavy pass's last tiles stream the light pass's K(0), K(1), V(0); Q before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_SEAM, 1},
     {"il8-ksplit-epi (small grids: 8 waves on one 128-row block, waves 0-3 take the even KV tiles and waves 4-7 the odd ones, merged through LDS)", 8, VF_DMA | VF_IL | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
+    {"il8-ksplit-pair-epi (the key-split kernel with causal blocks paired heavy+light per workgroup: two 128-row blocks per CU)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
@@ -70,7 +71,8 @@ constexpr int kSmallGridVariant = 32;     // il4-pair-epi (128-row query blocks,
 constexpr int kX4Variant = 33;            // il-x4-pair-epi
 constexpr int kX4D256Variant = 34;        // x4-d256-pair: the only kernel for head dims above 128
 constexpr int kSeamVariant = 35;          // il8-pair-dmaspread-epi-seam
-constexpr int kKSplitVariant = 36;        // il8-ksplit-epi: grids of at most one 128-row block per CU, non-causal
+constexpr int kKSplitVariant = 36;        // il8-ksplit-epi: grids of at most one 128-row block per CU
+constexpr int kKSplitPairVariant = 37;    // il8-ksplit-pair-epi: causal grids of at most two 128-row blocks per CU
 constexpr int kSplitVariant = 17;         // dma4-pair-2buf: the kernel whose grid can carry key chunks (tfa_fwd_splitkv)
 
 struct LaunchGeom {
@@ -87,7 +89,7 @@ static inline bool variant_built(int variant) {
   return true;
 #else
   return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant || variant == kX4Variant || variant == kX4D256Variant ||
-         variant == kKSplitVariant;
+         variant == kKSplitVariant || variant == kKSplitPairVariant;
 #endif
 }
 

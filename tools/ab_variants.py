@@ -15,7 +15,8 @@ CFG = {"cfg2": (4, 8, 1024, 64, torch.float16, False), "cfg3": (4, 32, 4096, 128
        "c8_2k": (1, 8, 2048, 128, torch.bfloat16, True), "c16_2k": (1, 16, 2048, 128, torch.bfloat16, True), "c32_2k": (1, 32, 2048, 128, torch.bfloat16, True),
        "c32_1k": (1, 32, 1024, 128, torch.bfloat16, True), "c64_512": (1, 64, 512, 128, torch.bfloat16, True), "c16_1k": (1, 16, 1024, 128, torch.bfloat16, True),
        "s16_4k": (1, 16, 4096, 128, torch.bfloat16, False), "s32_2k": (1, 32, 2048, 128, torch.bfloat16, False), "s8_8k": (1, 8, 8192, 128, torch.bfloat16, False),
-       "c2x16_2k": (2, 16, 2048, 64, torch.float16, True), "c4_16k": (1, 4, 16384, 128, torch.bfloat16, True)}
+       "c2x16_2k": (2, 16, 2048, 64, torch.float16, True), "c4_16k": (1, 4, 16384, 128, torch.bfloat16, True),
+       "c32_4k": (1, 32, 4096, 128, torch.bfloat16, True), "c2x16_4k": (2, 16, 4096, 64, torch.float16, True)}
 ap = argparse.ArgumentParser()
 ap.add_argument("--variants", default="30,33")
 ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4")
