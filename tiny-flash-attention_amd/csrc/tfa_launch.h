@@ -1,6 +1,6 @@
 // tfa_launch.h — host-side dispatch table shared by the per-(dtype, head-dim) instantiation units.
 #pragma once
-// The product library dispatches six kernels only (kDefaultVariant, kSmallGridVariant, kKSplitVariant, kSplitVariant and the two x4 ones below); every
+// The product library carries seven kernels only (kDefaultVariant, kSmallGridVariant, kKSplitVariant, kKSplitPairVariant, kSplitVariant and the two x4 ones below); every
 // other entry of kVariants is a measured dead end or an A/B arm kept for the record and is compiled only with
 // -DTFA_EXPERIMENTAL (make EXPERIMENTAL=1).  Without the flag those variant numbers are rejected (TFA_ERR_VARIANT).
 #include <hip/hip_runtime.h>
