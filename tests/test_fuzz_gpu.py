@@ -1,0 +1,18 @@
+"""Randomised cross-check of the dispatcher + every dispatched forward kernel against a device fp32 reference
+(tools/fuzz_fwd.py): random shapes, head dims, GQA ratios, layouts, scales, causal or not — the cases nobody thought of."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("args", [["--n", "200", "--seed", "7"], ["--n", "80", "--seed", "8", "--big"]])
+def test_fuzz_forward_against_device_fp32(args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_fwd.py")] + args, capture_output=True, text=True, timeout=900)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-12:])
+    assert r.returncode == 0, tail
+    assert " ok; kernels used" in r.stdout

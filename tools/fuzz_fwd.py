@@ -1,0 +1,69 @@
+"""Randomised cross-check of tfa_fwd (automatic dispatch) against a device fp32 reference: random B, H, Hk, Nq, Nk, D, dtype,
+causal, layout.  Bars: |out - ref| <= 1e-2 (the reference's own bar, flash_attention_cutlass/test.py:87), LSE 1e-3, the +inf
+pattern of rows that see no key.  usage: python tools/fuzz_fwd.py [--n 300] [--seed 0]"""
+import argparse, math, os, random, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tiny_flash_attention_amd import _lib, ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=300)
+ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--big", action="store_true", help="more heads and batches, longer sequences: grids that fill the chip (il8, paired key-split)")
+a = ap.parse_args()
+rng = random.Random(a.seed)
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(a.seed)
+bad, used = 0, {}
+for it in range(a.n):
+    D = rng.choice([64, 128, 128, 64, 32, 96, 256, 72, 192])
+    dt = rng.choice([torch.bfloat16, torch.float16])
+    causal = rng.random() < 0.6
+    Hk = rng.choice([1, 2, 4, 8])
+    H = Hk * rng.choice([1, 1, 2, 4])
+    B = rng.choice([1, 1, 2, 3])
+    if a.big:
+        Hk = rng.choice([4, 8, 16]); H = Hk * rng.choice([1, 2]); B = rng.choice([1, 2, 4])
+    kind = rng.random()
+    if kind < 0.35:
+        Nq = Nk = rng.choice([64, 128, 256, 512, 1024, 2048, 4096]) + rng.choice([0, 0, 1, -1, 17, -37])
+    elif kind < 0.7:
+        Nq, Nk = rng.randint(1, 700), rng.randint(1, 3000)
+    else:
+        Nq, Nk = rng.randint(1, 2500), rng.randint(1, 2500)
+    Nq, Nk = max(1, Nq), max(1, Nk)
+    if a.big and kind < 0.35:
+        Nq = Nk = rng.choice([1024, 2048, 4096, 8192]) + rng.choice([0, 0, 1, -1, 17, -37])
+    cap = 4e9 if a.big else 6e8
+    if B * H * Nq * Nk > cap:
+        Nk = max(1, int(cap / (B * H * Nq)))
+    layout = rng.choice(["bhnd", "bnhd"])
+    shp = (lambda n, h: (B, h, n, D)) if layout == "bhnd" else (lambda n, h: (B, n, h, D))
+    mk = lambda n, h: torch.empty(shp(n, h), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(dt)
+    q, k, v = mk(Nq, H), mk(Nk, Hk), mk(Nk, Hk)
+    sc = rng.choice([1.0 / math.sqrt(D), 0.05, 0.3])
+    out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout)
+    name = _lib.variant_name(_lib.variant_for(B, H, Hk, Nq, Nk, D, causal)).split(" ")[0]
+    used[name] = used.get(name, 0) + 1
+    tr = (lambda t: t) if layout == "bhnd" else (lambda t: t.transpose(1, 2))
+    qf, kf, vf = tr(q).float(), tr(k).float().repeat_interleave(H // Hk, 1), tr(v).float().repeat_interleave(H // Hk, 1)
+    s = torch.matmul(qf, kf.transpose(2, 3)) * sc
+    if causal:
+        i = torch.arange(Nq, device=dev)[:, None] + (Nk - Nq)
+        j = torch.arange(Nk, device=dev)[None, :]
+        s = s.masked_fill(j > i, float("-inf"))
+    lref = torch.logsumexp(s, dim=-1)
+    pm = torch.softmax(s, dim=-1).nan_to_num(0.0)
+    ref = torch.matmul(pm, vf)
+    o = tr(out).float()
+    d = (o - ref).abs().max().item()
+    fin = torch.isfinite(lref)
+    dl = (lse[fin] - lref[fin]).abs().max().item() if bool(fin.any()) else 0.0
+    pat = bool((torch.isinf(lse) == ~fin).all())
+    ok = bool(torch.isfinite(o).all()) and d <= 1e-2 and dl <= 1e-3 and pat
+    if not ok:
+        bad += 1
+        print(f"FAIL B{B} H{H} Hk{Hk} Nq{Nq} Nk{Nk} D{D} {dt} causal={causal} {layout} sc={sc:.3f} [{name}]: max|d|={d:.3e} lse {dl:.3e} inf-pattern {pat}", flush=True)
+print(f"{a.n - bad}/{a.n} ok; kernels used: {used}")
+sys.exit(1 if bad else 0)
