@@ -16,3 +16,8 @@ def test_fuzz_forward_against_device_fp32(args):
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-12:])
     assert r.returncode == 0, tail
     assert " ok; kernels used" in r.stdout
+
+
+def test_fuzz_backward_against_device_autograd():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_bwd.py"), "--n", "120", "--seed", "9"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "\n".join((r.stdout + r.stderr).splitlines()[-12:])
