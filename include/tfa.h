@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 103 /* 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
+#define TFA_VERSION 104 /* 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
 
 /* element types */
 enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1, TFA_F32 = 2 /* output only */ };
@@ -162,6 +162,11 @@ int tfa_merge(const float* o_parts, const float* lse_parts, int nparts, int64_t 
  * workspace: tfa_fwd_splitkv_workspace(p, splits) floats (16-byte aligned); negative return = TFA_ERR_*. */
 long long tfa_fwd_splitkv_workspace(const tfa_fwd_params* p, int splits);
 int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void* stream);
+/* The split count a host that can provide a workspace should use for *p: 1 = call tfa_fwd (the grid fills the chip, or the
+ * keys are too few to be worth a merge), >= 2 = call tfa_fwd_splitkv with that many chunks (decode-like shapes: B*H*ceil(Nq/128)
+ * workgroups on a quarter of the CUs or fewer and at least 4096 keys; measured 5-14x on B1 H32 Nq1 Nk16k..64k, B1 H8 Nq16 Nk32k).
+ * The reference-named bindings (attention_cutlass / attention_cuda / _kernels and their Python mirrors) follow it. */
+int tfa_fwd_suggest_splits(const tfa_fwd_params* p);
 
 /* ---- backward ------------------------------------------------------------
  * The reference has no backward pass; it saves softmax_lse for one ("LogSumExp save for backward",

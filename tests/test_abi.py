@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"include/tfa.h declares {n} but libtfa_hip.so does not export it"
     assert sorted(_lib.SYMBOLS) == names
-    assert L.tfa_version() == 103
+    assert L.tfa_version() == 104
 
 
 def _params(B=2, H=4, Hk=4, Nq=128, Nk=128, D=128, dtype=_lib.TFA_BF16, out_dtype=None, scale=0.1, base=0x10000):
@@ -139,6 +139,19 @@ def test_slices_beyond_2_gib_are_windowed_not_refused():
     p.D = 128
     a = p.k_stride; a[2] = 8 * 1024 * 1024                  # 16 MiB per row: even one 64-row tile window exceeds 2 GiB
     assert plan(p)[0] == -5
+
+
+def test_suggested_split_count():
+    # decode-like: few query rows, long K/V, too few workgroups -> chunks; prefill and short caches -> one pass
+    L = _lib.lib()
+    sug = lambda **kw: L.tfa_fwd_suggest_splits(C.byref(_params(**kw)))
+    assert sug(B=1, H=32, Hk=32, Nq=1, Nk=16384) == 8            # 32 workgroups -> 8 chunks fill 256 CUs
+    assert sug(B=1, H=8, Hk=8, Nq=16, Nk=32768) == 32
+    assert sug(B=1, H=8, Hk=8, Nq=16, Nk=5000) == 4              # at least 1024 keys per chunk
+    assert sug(B=8, H=32, Hk=32, Nq=1, Nk=16384) == 1            # 256 workgroups already
+    assert sug(B=1, H=32, Hk=32, Nq=1, Nk=2048) == 1             # short cache: the merge is not worth it
+    assert sug(B=4, H=32, Hk=32, Nq=4096, Nk=4096) == 1
+    assert sug(B=1, H=8, Hk=8, Nq=1, Nk=16384, D=256) == 1       # the split-KV kernel stops at D = 128
 
 
 def test_f32_out_and_gqa_accepted():

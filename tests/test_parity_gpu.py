@@ -676,6 +676,45 @@ def _import_from_lib(name):
         sys.path.remove(libdir)
 
 
+@pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D,causal", [
+    (torch.bfloat16, 1, 32, 32, 1, 16384, 128, True),       # one query row against a long cache: 32 workgroups without the split
+    (torch.bfloat16, 1, 8, 2, 16, 8192, 128, True),         # GQA, a few rows (speculative decoding / chunked prefill tail)
+    (torch.float16, 2, 4, 4, 3, 5000, 64, False),           # ragged key count, non-causal
+    (torch.bfloat16, 1, 4, 4, 200, 6000, 96, True),         # two query blocks, padded head dim
+])
+def test_reference_entry_points_split_decode_shapes(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal):
+    """Decode-like calls through the reference-named entry points (few query rows, long K/V): the bindings ask
+    tfa_fwd_suggest_splits and run tfa_fwd_splitkv (one launch carrying every key chunk + the LSE merge).  Same answer as the
+    one-pass kernel within the split-KV bars of tests/test_splitkv_gpu.py, same bits from the C++ modules and the Python mirror."""
+    import ctypes as C
+
+    from tiny_flash_attention_amd import _lib, ops
+
+    q, k, v = oracle.make_inputs(B, H, Nq, D, dtype, seed=51, Hk=Hk, Nk=Nk)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    sc = 1.0 / math.sqrt(D)
+    out0 = torch.empty_like(qd)
+    p = ops.make_params(qd, kd, vd, out0, None, causal, sc)
+    assert _lib.lib().tfa_fwd_suggest_splits(C.byref(p)) >= 2
+    out, lse = tfa.flash_attention_v2_cutlass(qd, kd, vd, causal, sc)
+    one, lse1 = ops.flash_attn_fwd(qd, kd, vd, causal, sc)
+    exact, lse_x = oracle.exact64(q, k, v, causal, sc, return_lse=True)
+    A = oracle.abs_weighted(q, k, v, causal, sc)
+    o = out.float().cpu()
+    assert (o - exact).abs().max().item() <= 1e-2
+    fin = torch.isfinite(lse_x)
+    assert bool((torch.isinf(lse.cpu()) == ~fin).all()) and (lse.cpu()[fin] - lse_x[fin]).abs().max().item() <= 1e-4
+    assert bool(((o - one.float().cpu()).abs() <= 2 * ulp16(exact, dtype) + 2.0 ** -8 * A + 1e-6).all())
+    # (attention_cutlass and attention_cuda take q, k, v of ONE shape, as in the reference: Nq != Nk goes through _kernels.flash_attn)
+    kern = _import_from_lib("_kernels")
+    assert torch.equal(kern.flash_attn(qd, kd, vd, causal, sc), out) and torch.equal(tfa.flash_attn(qd, kd, vd, causal, sc), out)
+    _lib.set_variant(30)                                   # a forced kernel variant means: run exactly that, no split
+    try:
+        assert _lib.lib().tfa_fwd_suggest_splits(C.byref(p)) == 1
+    finally:
+        _lib.set_variant(-1)
+
+
 def test_dropin_extension_module_attention_cuda(tfa, oracle, dev):
     """`from attention_cuda import self_attention_cuda, flash_attention_v1_cuda, flash_attention_v2_cuda` — the reference's
     own import line (flash_attention_cuda/self_attention.py:3).  Three names, one function: (q,k,v) -> out, non-causal,

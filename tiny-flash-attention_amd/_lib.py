@@ -29,6 +29,7 @@ SYMBOLS = (
     "tfa_merge",
     "tfa_fwd_splitkv",
     "tfa_fwd_splitkv_workspace",
+    "tfa_fwd_suggest_splits",
     "tfa_bwd",
     "tfa_bwd_plan",
     "tfa_bwd_work",
@@ -150,6 +151,8 @@ def lib():
     L.tfa_debug_set_trace.argtypes = [C.c_void_p]
     L.tfa_fwd_splitkv.restype = C.c_int
     L.tfa_fwd_splitkv.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p]
+    L.tfa_fwd_suggest_splits.restype = C.c_int
+    L.tfa_fwd_suggest_splits.argtypes = [P]
     L.tfa_fwd_splitkv_workspace.restype = C.c_longlong
     L.tfa_fwd_splitkv_workspace.argtypes = [P, C.c_int]
     L.tfa_merge.restype = C.c_int

@@ -23,6 +23,7 @@
 #include <torch/extension.h>
 
 #include <cmath>
+#include <cstring>
 #include <iostream>
 #include <vector>
 
@@ -52,6 +53,28 @@ void* current_stream(const torch::Tensor& q) {
   return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(q.device().index()).stream();
 }
 
+// (B,H,Nq,D) x (B,Hk,Nk,D) -> out (contiguous, allocated by the caller): one pass, or — decode-like shapes, as
+// tfa_fwd_suggest_splits says — split-KV in one launch with a scratch tensor for the partial results.
+int run_forward(const torch::Tensor& q, const torch::Tensor& k, const torch::Tensor& v, torch::Tensor& out, float* lse, bool is_causal,
+                float softmax_scale, int dtype) {
+  tfa_fwd_params p;
+  std::memset(&p, 0, sizeof p);
+  p.q = q.data_ptr(); p.k = k.data_ptr(); p.v = v.data_ptr(); p.out = out.data_ptr(); p.lse = lse;
+  p.B = q.size(0); p.H = q.size(1); p.Hk = k.size(1); p.Nq = q.size(2); p.Nk = k.size(2); p.D = q.size(3);
+  const torch::Tensor* ts[4] = {&q, &k, &v, &out};
+  int64_t* st[4] = {p.q_stride, p.k_stride, p.v_stride, p.o_stride};
+  for (int i = 0; i < 4; ++i) { st[i][0] = ts[i]->stride(0); st[i][1] = ts[i]->stride(1); st[i][2] = ts[i]->stride(2); }
+  p.softmax_scale = softmax_scale; p.is_causal = is_causal ? 1 : 0; p.dtype = dtype; p.out_dtype = dtype;
+  const int splits = out.is_contiguous() ? tfa_fwd_suggest_splits(&p) : 1;
+  if (splits > 1) {
+    const long long need = tfa_fwd_splitkv_workspace(&p, splits);
+    if (need < 0) return (int)need;
+    auto ws = torch::empty({need}, q.options().dtype(torch::kFloat32));
+    return tfa_fwd_splitkv(&p, splits, ws.data_ptr<float>(), current_stream(q));
+  }
+  return tfa_fwd(&p, current_stream(q));
+}
+
 }  // namespace
 
 #if TFA_BINDING == 1
@@ -71,9 +94,8 @@ static std::vector<torch::Tensor> flash_attention_v2_cutlass(torch::Tensor q, to
   auto out = torch::empty_like(q);
   auto softmax_lse = torch::empty({bs, head, seqlen}, q.options().dtype(torch::kFloat32));
 
-  const int st = tfa_fwd_bhnd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
-                              softmax_lse.data_ptr<float>(), bs, head, seqlen, dim, softmax_scale,
-                              is_causal ? 1 : 0, dtype, current_stream(q));
+  (void)dim;
+  const int st = run_forward(q, k, v, out, softmax_lse.data_ptr<float>(), is_causal, softmax_scale, dtype);
   TORCH_CHECK(st == 0, tfa_strerror(st));
   return {out, softmax_lse};
 }
@@ -95,8 +117,8 @@ static torch::Tensor attention_3arg(const torch::Tensor& q, const torch::Tensor&
   const float sm_scale = 1.f / std::sqrt(static_cast<float>(dim));
   const c10::DeviceGuard guard(q.device());
   auto out = torch::empty_like(q);
-  const int st = tfa_fwd_bhnd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nullptr, bs, head, seqlen, dim, sm_scale, 0, dtype,
-                              current_stream(q));
+  (void)bs; (void)head; (void)seqlen;
+  const int st = run_forward(q, k, v, out, nullptr, false, sm_scale, dtype);
   TORCH_CHECK(st == 0, tfa_strerror(st));
   return out;
 }
@@ -125,15 +147,7 @@ static torch::Tensor attn_strided(const torch::Tensor& q, const torch::Tensor& k
   const int dtype = dtype_code(q, k, v, who);
   const c10::DeviceGuard guard(q.device());
   auto out = torch::empty(q.sizes(), q.options());
-  tfa_fwd_params p;
-  std::memset(&p, 0, sizeof p);
-  p.q = q.data_ptr(); p.k = k.data_ptr(); p.v = v.data_ptr(); p.out = out.data_ptr(); p.lse = nullptr;
-  p.B = q.size(0); p.H = q.size(1); p.Hk = k.size(1); p.Nq = q.size(2); p.Nk = k.size(2); p.D = q.size(3);
-  const torch::Tensor* ts[4] = {&q, &k, &v, &out};
-  int64_t* st[4] = {p.q_stride, p.k_stride, p.v_stride, p.o_stride};
-  for (int i = 0; i < 4; ++i) { st[i][0] = ts[i]->stride(0); st[i][1] = ts[i]->stride(1); st[i][2] = ts[i]->stride(2); }
-  p.softmax_scale = softmax_scale; p.is_causal = is_causal ? 1 : 0; p.dtype = dtype; p.out_dtype = dtype;
-  const int rc = tfa_fwd(&p, current_stream(q));
+  const int rc = run_forward(q, k, v, out, nullptr, is_causal, softmax_scale, dtype);
   TORCH_CHECK(rc == 0, tfa_strerror(rc));
   return out;
 }

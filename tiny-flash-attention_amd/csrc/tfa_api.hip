@@ -280,6 +280,18 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   return tfa_merge(ws_o, ws_l, ns, rows, p->D, rows * p->D, rows, p->out, p->out_dtype, p->lse, stream);
 }
 
+int tfa_fwd_suggest_splits(const tfa_fwd_params* p) {
+  if (!p || g_variant >= 0) return 1;                     // a forced kernel variant means: run exactly that
+  if (p->D > 128 || p->kv_offset != 0 || p->nk_total != 0 || p->B <= 0 || p->H <= 0 || p->Nq <= 0) return 1;
+  const long long blocks = (long long)p->B * p->H * ((p->Nq + 127) / 128);
+  const int cus = num_cus();
+  if (blocks * 4 > cus || p->Nk < 4096) return 1;
+  long long s = cus / blocks;
+  if (s > p->Nk / 1024) s = p->Nk / 1024;
+  if (s > 32) s = 32;
+  return s >= 2 ? (int)s : 1;
+}
+
 int tfa_fwd_variant(const tfa_fwd_params* p) {
   tfa::LaunchGeom g = {0, 0, 0};
   const int st = run(p, nullptr, &g, true);

@@ -32,12 +32,13 @@ def _strides_bhnd(t, layout):
 
 
 def flash_attn_fwd(q, k, v, is_causal=False, softmax_scale=None, *, layout="bhnd", out_f32=False,
-                   return_lse=True, out=None, kv_offset=0, nk_total=None):
+                   return_lse=True, out=None, kv_offset=0, nk_total=None, auto_split=False):
     """General forward: q (B,H,Nq,D) / k,v (B,Hk,Nk,D) for ``layout='bhnd'`` or
     (B,N,H,D) for ``layout='bnhd'``; any batch/head/row strides, unit stride along D.
     Returns ``(out, lse)``; ``out`` has q's shape (fp32 when ``out_f32``), ``lse`` is (B,H,Nq) fp32.
     Maps onto tfa_fwd (include/tfa.h); semantics per flash_attention_c/csrc/attn.cpp:101-169 and
-    flash_attention_cutlass/csrc/flash_attention.cu:536-630."""
+    flash_attention_cutlass/csrc/flash_attention.cu:536-630.  ``auto_split``: decode-like shapes (few query rows, long K/V)
+    go through tfa_fwd_splitkv with the chunk count tfa_fwd_suggest_splits names (what the reference-named entry points do)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         if not t.is_cuda:
             raise RuntimeError(f"{n} must be a CUDA tensor")
@@ -87,9 +88,18 @@ def flash_attn_fwd(q, k, v, is_causal=False, softmax_scale=None, *, layout="bhnd
     p.out_dtype = _lib.TFA_F32 if out.dtype == torch.float32 else _DT[out.dtype]
     p.kv_offset = int(kv_offset)                     # split-KV: k, v are keys [kv_offset, kv_offset+Nk) of nk_total
     p.nk_total = 0 if nk_total is None else int(nk_total)
+    L = _lib.lib()
+    splits = L.tfa_fwd_suggest_splits(C.byref(p)) if (auto_split and layout == "bhnd" and out.is_contiguous()) else 1
     with torch.cuda.device(q.device):
         stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().tfa_fwd(C.byref(p), C.c_void_p(stream)))
+        if splits > 1:
+            need = L.tfa_fwd_splitkv_workspace(C.byref(p), int(splits))
+            if need < 0:
+                _lib.check(int(need))
+            ws = torch.empty((int(need),), dtype=torch.float32, device=q.device)
+            _lib.check(L.tfa_fwd_splitkv(C.byref(p), int(splits), ws.data_ptr(), C.c_void_p(stream)))
+        else:
+            _lib.check(L.tfa_fwd(C.byref(p), C.c_void_p(stream)))
     return out, lse
 
 
@@ -244,7 +254,7 @@ def flash_attention_v2_cutlass(q, k, v, is_causal, softmax_scale):
     _check_input(q, "q")
     _check_input(k, "k")
     _check_input(v, "v")
-    out, lse = flash_attn_fwd(q, k, v, bool(is_causal), float(softmax_scale))
+    out, lse = flash_attn_fwd(q, k, v, bool(is_causal), float(softmax_scale), auto_split=True)
     return [out, lse]
 
 
@@ -254,7 +264,7 @@ def flash_attention_v2_cuda(q, k, v):
     _check_input(q, "q")
     _check_input(k, "k")
     _check_input(v, "v")
-    out, _ = flash_attn_fwd(q, k, v, False, 1.0 / math.sqrt(q.shape[-1]), return_lse=False)
+    out, _ = flash_attn_fwd(q, k, v, False, 1.0 / math.sqrt(q.shape[-1]), return_lse=False, auto_split=True)
     return out
 
 
@@ -269,7 +279,7 @@ def flash_attn(q, k, v, is_causal, softmax_scale):
     (flash_attention_c/csrc/attn.cpp:237-262).  Same math as the CPU sibling, including its
     bottom-right-aligned causal mask for Nq != Nk (attn.cpp:121-124) and strided inputs
     (attn.cpp:171-203); tensors live on the GPU and are 16-bit here."""
-    out, _ = flash_attn_fwd(q, k, v, bool(is_causal), float(softmax_scale), return_lse=False)
+    out, _ = flash_attn_fwd(q, k, v, bool(is_causal), float(softmax_scale), return_lse=False, auto_split=True)
     return out
 
 
