@@ -286,6 +286,7 @@ int tfa_fwd_suggest_splits(const tfa_fwd_params* p) {
   const long long blocks = (long long)p->B * p->H * ((p->Nq + 127) / 128);
   const int cus = num_cus();
   if (blocks * 4 > cus || p->Nk < 4096) return 1;
+  if (p->is_causal && (long long)p->Nq * 4 > p->Nk) return 1;   // causal prefill: the late chunks serve few rows (measured 0.93-1.06x)
   long long s = cus / blocks;
   if (s > p->Nk / 1024) s = p->Nk / 1024;
   if (s > 32) s = 32;
