@@ -175,8 +175,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
     if (nsplit > 1) {                                            // descriptor over the chunk only: OOB rows read as zeros
       koff = (long long)k.sp * p.chunk * p.ks_n;
       voff = (long long)k.sp * p.chunk * p.vs_n;
-      kb = k.nk > 0 ? (unsigned)(((long long)(k.nk - 1) * p.ks_n + D) * 2) : 0u;
-      vb = k.nk > 0 ? (unsigned)(((long long)(k.nk - 1) * p.vs_n + D) * 2) : 0u;
+      // (extent of nk rows of the VALID width p.dv: with the kernel's width D here, a head dim below D would leave the first
+      //  row behind the chunk readable — for the last chunk of the last head that is memory behind the tensor, and P = 0
+      //  times whatever lies there is NaN as soon as it is not finite; found by tools/fuzz_fwd.py --decode)
+      kb = k.nk > 0 ? (unsigned)(((long long)(k.nk - 1) * p.ks_n + p.dv) * 2) : 0u;
+      vb = k.nk > 0 ? (unsigned)(((long long)(k.nk - 1) * p.vs_n + p.dv) * 2) : 0u;
     }
     k.k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h + koff), 0, kb, 0x00020000);
     k.v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h + voff), 0, vb, 0x00020000);

@@ -10,6 +10,7 @@ from tiny_flash_attention_amd import _lib, ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=300)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--decode", action="store_true", help="few query rows against long K/V through the reference-style path (auto_split: tfa_fwd_suggest_splits + tfa_fwd_splitkv)")
 ap.add_argument("--big", action="store_true", help="more heads and batches, longer sequences: grids that fill the chip (il8, paired key-split)")
 a = ap.parse_args()
 rng = random.Random(a.seed)
@@ -35,16 +36,24 @@ for it in range(a.n):
     Nq, Nk = max(1, Nq), max(1, Nk)
     if a.big and kind < 0.35:
         Nq = Nk = rng.choice([1024, 2048, 4096, 8192]) + rng.choice([0, 0, 1, -1, 17, -37])
+    if a.decode:
+        D = rng.choice([64, 128, 96, 32])
+        B, Hk = rng.choice([1, 1, 2]), rng.choice([1, 2, 4, 8]); H = Hk * rng.choice([1, 2, 4])
+        Nq, Nk = rng.choice([1, 1, 2, 7, 16, 33, 128, 200]), rng.randint(4096, 40000)
+        layout = "bhnd"
     cap = 4e9 if a.big else 6e8
     if B * H * Nq * Nk > cap:
         Nk = max(1, int(cap / (B * H * Nq)))
-    layout = rng.choice(["bhnd", "bnhd"])
+    layout = rng.choice(["bhnd", "bnhd"]) if not a.decode else "bhnd"
     shp = (lambda n, h: (B, h, n, D)) if layout == "bhnd" else (lambda n, h: (B, n, h, D))
     mk = lambda n, h: torch.empty(shp(n, h), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(dt)
     q, k, v = mk(Nq, H), mk(Nk, Hk), mk(Nk, Hk)
     sc = rng.choice([1.0 / math.sqrt(D), 0.05, 0.3])
-    out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout)
+    out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout, auto_split=a.decode)
     name = _lib.variant_name(_lib.variant_for(B, H, Hk, Nq, Nk, D, causal)).split(" ")[0]
+    if a.decode:
+        import ctypes as C
+        name = "splits=%d" % _lib.lib().tfa_fwd_suggest_splits(C.byref(ops.make_params(q, k, v, out, lse, causal, sc)))
     used[name] = used.get(name, 0) + 1
     tr = (lambda t: t) if layout == "bhnd" else (lambda t: t.transpose(1, 2))
     qf, kf, vf = tr(q).float(), tr(k).float().repeat_interleave(H // Hk, 1), tr(v).float().repeat_interleave(H // Hk, 1)
@@ -64,6 +73,11 @@ for it in range(a.n):
     ok = bool(torch.isfinite(o).all()) and d <= 1e-2 and dl <= 1e-3 and pat
     if not ok:
         bad += 1
-        print(f"FAIL B{B} H{H} Hk{Hk} Nq{Nq} Nk{Nk} D{D} {dt} causal={causal} {layout} sc={sc:.3f} [{name}]: max|d|={d:.3e} lse {dl:.3e} inf-pattern {pat}", flush=True)
+        print(f"FAIL #{it} B{B} H{H} Hk{Hk} Nq{Nq} Nk{Nk} D{D} {dt} causal={causal} {layout} sc={sc:.3f} [{name}]: max|d|={d:.3e} lse {dl:.3e} inf-pattern {pat}", flush=True)
+        nf = (~torch.isfinite(o)).nonzero()
+        if len(nf):
+            print(f"     non-finite: {len(nf)} elements; batches {sorted(set(nf[:, 0].tolist()))} heads {sorted(set(nf[:, 1].tolist()))} rows {sorted(set(nf[:, 2].tolist()))[:10]} cols {sorted(set(nf[:, 3].tolist()))[:16]}", flush=True)
+            out2, _ = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout, auto_split=a.decode)   # again, same inputs: deterministic?
+            print(f"     second run of the same call: {int((~torch.isfinite(out2.float())).sum())} non-finite", flush=True)
 print(f"{a.n - bad}/{a.n} ok; kernels used: {used}")
 sys.exit(1 if bad else 0)
