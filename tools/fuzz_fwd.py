@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(a.seed)
 bad, used = 0, {}
 for it in range(a.n):
-    D = rng.choice([64, 128, 128, 64, 32, 96, 256, 72, 192])
+    D = rng.choice([64, 128, 128, 64, 32, 96, 256, 72, 192, 136, 200, 8, 40, 248])
     dt = rng.choice([torch.bfloat16, torch.float16])
     causal = rng.random() < 0.6
     Hk = rng.choice([1, 2, 4, 8])
