@@ -46,10 +46,19 @@ for it in range(a.n):
         Nk = max(1, int(cap / (B * H * Nq)))
     layout = rng.choice(["bhnd", "bnhd"]) if not a.decode else "bhnd"
     shp = (lambda n, h: (B, h, n, D)) if layout == "bhnd" else (lambda n, h: (B, n, h, D))
-    mk = lambda n, h: torch.empty(shp(n, h), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(dt)
+    pad = rng.choice([0, 0, 0, 8, 24, 64])               # row stride D + pad: rows that do not follow each other in memory
+    def mk(n, h):
+        full = torch.empty(shp(n, h)[:3] + (D + pad,), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(dt)
+        return full[..., :D] if pad else full
     q, k, v = mk(Nq, H), mk(Nk, Hk), mk(Nk, Hk)
+    mode = "auto" if a.decode else rng.choice(["16", "16", "16", "f32", "chunks"])
     sc = rng.choice([1.0 / math.sqrt(D), 0.05, 0.3])
-    out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout, auto_split=a.decode)
+    if mode == "f32":                                    # fp32 debug output
+        out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout, out_f32=True)
+    elif mode == "chunks" and layout == "bhnd" and Nk >= 128 and D <= 128:   # python-driven partial passes + tfa_merge
+        out, lse = ops.flash_attn_fwd_splitkv(q, k, v, causal, sc, splits=rng.choice([2, 3, 5]), native=False)
+    else:
+        out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout, auto_split=a.decode)
     name = _lib.variant_name(_lib.variant_for(B, H, Hk, Nq, Nk, D, causal)).split(" ")[0]
     if a.decode:
         import ctypes as C
