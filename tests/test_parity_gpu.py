@@ -66,10 +66,18 @@ def check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype, var=None):
     if var is None:
         var = _lib.variant_for(q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3], causal)
     emulate = oracle.tiled_emulation_lazy if _lib.lazy_reference(var) else oracle.tiled_emulation
+    # GQA with few query rows and automatic dispatch: the library runs the G query heads of a K/V head as G x Nq rows of one
+    # problem (tfa_api.hip: pack_gqa_rows) — same math, but a wave's 32 rows (the unit that re-bases together) now span heads
+    Bq, Hq, Nqq, Dq = q.shape
+    G = Hq // k.shape[1]
+    packed = _lib.get_variant() < 0 and G > 1 and G * Nqq <= 128 and (Nqq == 1 or not causal)
+    qe, ce = (q.reshape(Bq, k.shape[1], G * Nqq, Dq), False) if packed else (q, causal)
     if var in (KSPLIT, KSPLIT_PAIR):                    # two wave groups over the even / odd key tiles, merged
-        emu, lse_e = oracle.ksplit_emulation(q, k, v, causal, sc, 64, return_lse=True)
+        emu, lse_e = oracle.ksplit_emulation(qe, k, v, ce, sc, 64, return_lse=True)
     else:
-        emu, lse_e = emulate(q, k, v, causal, sc, 64, return_lse=True)
+        emu, lse_e = emulate(qe, k, v, ce, sc, 64, return_lse=True)
+    if packed:
+        emu, lse_e = emu.reshape(q.shape), lse_e.reshape(Bq, Hq, Nqq)
     exact, lse_x = oracle.exact64(q, k, v, causal, sc, return_lse=True)
     A = oracle.abs_weighted(q, k, v, causal, sc)
     o16 = out16.float().cpu()
@@ -713,6 +721,52 @@ def test_reference_entry_points_split_decode_shapes(tfa, oracle, dev, dtype, B, 
         assert _lib.lib().tfa_fwd_suggest_splits(C.byref(p)) == 1
     finally:
         _lib.set_variant(-1)
+
+
+@pytest.mark.parametrize("layout", ["bhnd", "bnhd"])
+@pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D,causal", [
+    (torch.bfloat16, 3, 32, 8, 1, 1500, 128, True),         # decode, G = 4: four query heads per K/V head become four rows
+    (torch.float16, 2, 16, 1, 1, 700, 64, True),            # MQA: all 16 heads of a batch are one 16-row problem
+    (torch.bfloat16, 2, 8, 2, 3, 600, 128, False),          # a few rows, non-causal: packed when the heads are adjacent (bhnd)
+    (torch.bfloat16, 2, 8, 2, 3, 600, 128, True),           # a few rows, causal: rows of different positions -> not packed
+    (torch.float16, 1, 64, 2, 4, 500, 96, False),           # G x Nq = 128: exactly one query block
+    (torch.float16, 1, 64, 2, 5, 500, 64, False),           # G x Nq = 160: beyond one block -> not packed
+])
+def test_gqa_query_heads_packed_as_rows(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, layout):
+    """GQA / MQA with few query rows: the library describes the G query heads of a K/V head as G x Nq rows of one problem
+    (tfa_api.hip: pack_gqa_rows) so K/V stream once per K/V head.  Same answer as without the re-description (debug flag
+    4096) within the P-rounding bound, same oracle bars, and the grid shrinks G-fold when it applies."""
+    import ctypes as C
+
+    from tiny_flash_attention_amd import _lib, ops
+
+    q, k, v = oracle.make_inputs(B, H, Nq, D, dtype, seed=61, Hk=Hk, Nk=Nk)
+    sc = 1.0 / math.sqrt(D)
+    tr = (lambda t: t.to(dev)) if layout == "bhnd" else (lambda t: t.to(dev).transpose(1, 2).contiguous())
+    qd, kd, vd = tr(q), tr(k), tr(v)
+    out, lse = ops.flash_attn_fwd(qd, kd, vd, causal, sc, layout=layout)
+    _lib.debug_set_flags(4096)
+    try:
+        ref_out, ref_lse = ops.flash_attn_fwd(qd, kd, vd, causal, sc, layout=layout)
+        p = ops.make_params(qd, kd, vd, torch.empty_like(qd), None, causal, sc, layout=layout)
+        g0, g1, blk, lds = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(_lib.lib().tfa_fwd_plan(C.byref(p), C.byref(g0), C.byref(blk), C.byref(lds)))
+    finally:
+        _lib.debug_set_flags(0)
+    _lib.check(_lib.lib().tfa_fwd_plan(C.byref(p), C.byref(g1), C.byref(blk), C.byref(lds)))
+    G = H // Hk
+    adjacent = layout == "bhnd"
+    expect_packed = G * Nq <= 128 and (Nq == 1 or (not causal and adjacent))
+    assert (g1.value * G == g0.value) == expect_packed, (g0.value, g1.value)
+    back = (lambda t: t) if layout == "bhnd" else (lambda t: t.transpose(1, 2))
+    o, o_ref = back(out).float().cpu(), back(ref_out).float().cpu()
+    exact, lse_x = oracle.exact64(q, k, v, causal, sc, return_lse=True)
+    A = oracle.abs_weighted(q, k, v, causal, sc)
+    assert (o - exact).abs().max().item() <= 1e-2
+    assert (lse.cpu() - lse_x).abs().max().item() <= 1e-4
+    assert bool(((o - o_ref).abs() <= 2 * ulp16(exact, dtype) + 2.0 ** -8 * A + 1e-6).all())
+    if not expect_packed:
+        assert torch.equal(out, ref_out) and torch.equal(lse, ref_lse)
 
 
 def test_dropin_extension_module_attention_cuda(tfa, oracle, dev):

@@ -142,7 +142,36 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   return TFA_OK;
 }
 
-int run(const tfa_fwd_params* p, void* stream, tfa::LaunchGeom* geom, bool dry) {
+// GQA / MQA with few query rows (decode): the G = H/Hk query heads that share a K/V head are G x Nq ROWS of one problem over
+// that head's keys — the same bytes described differently (head stride G times larger, rows one head apart), so K and V are
+// streamed once per K/V head instead of once per query head and the grid shrinks G-fold.  One query row: any strides, and
+// a causal mask hides nothing from it (its position is the last key), so the packed problem is non-causal.  More rows: only
+// non-causal and with the heads of q / out adjacent in memory (rows of consecutive heads are then equidistant).  The LSE layout
+// (B,H,Nq) is the packed problem's (B,Hk,G*Nq) as it stands.  Returns false when *p is not such a problem.
+bool pack_gqa_rows(const tfa_fwd_params* p, tfa_fwd_params* o) {
+  if (!p || p->Hk <= 0 || p->H <= p->Hk || p->H % p->Hk != 0 || p->Nq <= 0 || p->Nk <= 0) return false;
+  if (p->kv_offset != 0 || p->nk_total != 0) return false;
+  const int G = p->H / p->Hk;
+  const bool one_row = p->Nq == 1;
+  const bool adjacent = !p->is_causal && p->q_stride[1] == (int64_t)p->Nq * p->q_stride[2] && p->o_stride[1] == (int64_t)p->Nq * p->o_stride[2];
+  if (!one_row && !adjacent) return false;
+  if ((long long)G * p->Nq > 128) return false;          // beyond one query block nothing is shared any more
+  *o = *p;
+  o->H = p->Hk;
+  o->Nq = G * p->Nq;
+  if (one_row) {
+    o->q_stride[2] = p->q_stride[1];
+    o->o_stride[2] = p->o_stride[1];
+    o->is_causal = 0;
+  }
+  o->q_stride[1] = (int64_t)G * p->q_stride[1];
+  o->o_stride[1] = (int64_t)G * p->o_stride[1];
+  return true;
+}
+
+int run(const tfa_fwd_params* p_in, void* stream, tfa::LaunchGeom* geom, bool dry) {
+  tfa_fwd_params packed;
+  const tfa_fwd_params* p = (g_variant < 0 && !(g_dbg_flags & 4096) && pack_gqa_rows(p_in, &packed)) ? &packed : p_in;
   const int variant = pick_variant(p);
   tfa::KArgs a;
   const int st = validate(p, &a, variant);
@@ -260,6 +289,10 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   q.lse = ws_l;
   q.out_dtype = TFA_F32;
   q.o_stride[0] = (int64_t)p->H * p->Nq * p->D; q.o_stride[1] = (int64_t)p->Nq * p->D; q.o_stride[2] = p->D;
+  {
+    tfa_fwd_params qp;                                    // GQA decode: one stream of K/V per K/V head (the workspace rows keep their order)
+    if (!(g_dbg_flags & 4096) && pack_gqa_rows(&q, &qp)) q = qp;
+  }
   const int variant = tfa::kSplitVariant;                 // the LDS-DMA kernel carries the chunk dimension in its grid
   tfa::KArgs a;
   st = validate(&q, &a, variant);
@@ -271,7 +304,7 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   if ((long long)a.nbh * a.nwork * ns >= (long long)0x7fffffff) return TFA_ERR_SHAPE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipError_t e;
-  const bool causal = p->is_causal != 0;
+  const bool causal = q.is_causal != 0;                   // (the packed one-row problem is non-causal)
   if (p->dtype == TFA_BF16)
     e = (p->D > 64) ? tfa::launch_fwd<__bf16, 128>(a, causal, true, variant, s, nullptr, false) : tfa::launch_fwd<__bf16, 64>(a, causal, true, variant, s, nullptr, false);
   else
@@ -280,8 +313,10 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   return tfa_merge(ws_o, ws_l, ns, rows, p->D, rows * p->D, rows, p->out, p->out_dtype, p->lse, stream);
 }
 
-int tfa_fwd_suggest_splits(const tfa_fwd_params* p) {
-  if (!p || g_variant >= 0) return 1;                     // a forced kernel variant means: run exactly that
+int tfa_fwd_suggest_splits(const tfa_fwd_params* p_in) {
+  if (!p_in || g_variant >= 0) return 1;                  // a forced kernel variant means: run exactly that
+  tfa_fwd_params packed;
+  const tfa_fwd_params* p = pack_gqa_rows(p_in, &packed) ? &packed : p_in;
   if (p->D > 128 || p->kv_offset != 0 || p->nk_total != 0 || p->B <= 0 || p->H <= 0 || p->Nq <= 0) return 1;
   const long long blocks = (long long)p->B * p->H * ((p->Nq + 127) / 128);
   const int cus = num_cus();
@@ -297,7 +332,8 @@ int tfa_fwd_variant(const tfa_fwd_params* p) {
   tfa::LaunchGeom g = {0, 0, 0};
   const int st = run(p, nullptr, &g, true);
   if (st != 0) return st > 0 ? TFA_ERR_SHAPE : st;
-  return pick_variant(p);
+  tfa_fwd_params packed;                                  // (the problem run() actually dispatches: see pack_gqa_rows)
+  return pick_variant((g_variant < 0 && !(g_dbg_flags & 4096) && pack_gqa_rows(p, &packed)) ? &packed : p);
 }
 
 int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, float* avg_ms) {
