@@ -44,6 +44,8 @@ constexpr int VF_IL_SEAM = 2097152;      // causal pairs: the heavy pass's last 
 constexpr int VF_IL_KSPLIT = 1 << 25;    // small non-causal grids: the 8 waves work on ONE 128-row query block — waves 0-3 ("group 0") take the even
                                          // KV tiles, waves 4-7 the odd ones, each group with its own K/V ring in LDS; group 1 hands its O, m, l
                                          // to group 0 through LDS at the end.  Two waves per SIMD where 128-row workgroups alone would leave one.
+constexpr int VF_IL_IDLE = 1 << 26;      // waves whose 32 rows all lie behind the last query row skip the tile work (decode-like problems: one
+                                         // query block with one valid wave).  Its own instantiation: the flag costs the causal headline 0.5 %
 constexpr int VF_IL_WINDOWED = 1 << 24;  // K/V tiles through per-tile descriptors (rsrc_at): a (b,h) slice may exceed 2 GiB.  ~6 % slower (a fresh
                                          // descriptor per tile: ~14 SALU + the SGPR->VMEM wait states), so only launched when needed
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
@@ -460,6 +462,10 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 
     // tiles this wave computes: 0 .. nact-1 (causal: the waves of a block stop at different tiles)
     const int nact = (wave_last_tile + 1 < nt_own) ? (wave_last_tile + 1) : nt_own;
+    // A wave whose 32 rows all lie behind the last query row computes nothing: decode-like problems have one valid wave per
+    // block, and the tile rate — hence the K/V streaming rate — is then that one wave's.  (A separate flag, not a smaller
+    // nact: non-causal kernels keep nact == nt as a compile-time fact and lose 2 % without it.)
+    const bool idle_wave = (VF & VF_IL_IDLE) != 0 && wave_row0 >= p.Nq;
     // first tile of this wave that needs masking (causal diagonal or ragged tail); nact if none
     int fm = nact;
     {
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tt][r]);
       mout = pair_max(mx);
     };
-    if (nact > 0) {
+    if (nact > 0 && !idle_wave) {
       qk_burst(0, 0, sA, mA);
       mref = fmaxf(mref, mA * sc);                       // first re-base for free: O = 0 and l = 0 so far
     }
@@ -641,6 +647,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     using C1 = std::integral_constant<int, 1>;
     using MN = std::integral_constant<bool, false>;
     using MY = std::integral_constant<bool, true>;
+    if (!idle_wave)
 #pragma nounroll
     for (int j = 0; j < nact; j += 2) {
       if (j + 1 < nact && !trigger(mA)) {
@@ -658,7 +665,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       }
     }
 #pragma nounroll
-    for (int j = nact; j < nt; ++j) {                    // tiles of the block this wave does not touch
+    for (int j = idle_wave ? 0 : nact; j < nt; ++j) {    // tiles of the block this wave does not touch
       if (j + 2 < nt) dma_k(j + 2, j & 1);
       else if (seam) dma_k(j + 2 - nt, j & 1);
       if (j + 1 < nt) dma_v(j + 1, (j & 1) ^ 1);
