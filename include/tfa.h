@@ -115,7 +115,10 @@ int tfa_version(void);
 const char* tfa_strerror(int status);
 
 /* Launch the forward pass described by *p on HIP stream `stream` (NULL = default stream).
- * Asynchronous: returns after enqueueing. */
+ * Asynchronous: returns after enqueueing.  Never allocates.  The kernel is chosen from the problem's size (256-row blocks,
+ * 128-row blocks, keys split inside the workgroup for grids smaller than the chip, the 256-wide kernel for D > 128); with
+ * Hk < H and one query row per head (batched decode) the H/Hk query heads of a K/V head are run as rows of one problem, so
+ * K and V stream once per K/V head.  Results do not depend on those choices beyond the rounding of P to 16 bits. */
 int tfa_fwd(const tfa_fwd_params* p, void* stream);
 
 /* Convenience form for the reference's layout: q,k,v,out contiguous (B,H,N,D), Nq == Nk == N,
