@@ -54,6 +54,9 @@ int pick_variant(const tfa_fwd_params* p) {
   // causal, up to two 128-row blocks per CU, long sequences: the same kernel with the blocks paired heavy+light (one round of
   // equal workgroups, two waves per SIMD): B1 H16 N4096 +4 %, B1 H8 N8192 +7 %, B1 H4 N16384 +11 % over il4; N=2048: -2..+5 %
   if (whole_seq && one_descriptor && p->is_causal && blocks128 <= 2 * cus && p->Nk >= 4096) return tfa::kKSplitPairVariant;
+  // at most 128 query rows (decode, cross-attention onto few queries): a 256-row block would be half idle; 128-row blocks put two
+  // workgroups on a CU and keep twice the K/V bytes in flight (B32 H32 Nq1 Nk16384 D64: K/V at 6.1 vs 5.0 TB/s, D128: 6.1 vs 6.0)
+  if (p->Nq <= 128) return tfa::kSmallGridVariant;
   // non-causal, at least one 256-row block per CU: the 8-wave kernel already has two waves per SIMD everywhere
   // (B1 H16 N4096: 1160 vs 1091 TF for il4, B1 H32 N2048: 1098 vs 1038)
   if (!p->is_causal && blocks256 >= cus) return tfa::kDefaultVariant;
