@@ -207,7 +207,15 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   int bh, wi;
   {
     const int id = blockIdx.x;
-    if ((p.nbh & 7) == 0) {
+    const int G = p.H / p.Hk;
+    if (G > 1 && ((p.B * p.Hk) & 7) == 0) {
+      // GQA: the G query heads of a K/V head stay on ONE XCD (its K/V tiles are fetched into one L2 instead of G), K/V heads
+      // round-robin over the XCDs: XCD x works through K/V heads x, x+8, ... and, inside one, through its query heads
+      const int x = id & 7, s = id >> 3;
+      const int per = G * p.nwork, kg = x + 8 * (s / per), r = s % per;
+      bh = (kg / p.Hk) * p.H + (kg % p.Hk) * G + r / p.nwork;
+      wi = r % p.nwork;
+    } else if ((p.nbh & 7) == 0) {
       const int x = id & 7, s = id >> 3;
       bh = x + 8 * (s / p.nwork);
       wi = s % p.nwork;
