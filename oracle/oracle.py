@@ -174,7 +174,7 @@ def tiled_emulation(q, k, v, is_causal, softmax_scale, block_n=64, p_dtype=None,
 
 
 def tiled_emulation_lazy(q, k, v, is_causal, softmax_scale, block_n=64, group=32, thresh=8.0, p_dtype=None,
-                         return_lse=False, key_pos=None, nk_total=None):
+                         return_lse=False, key_pos=None, nk_total=None, row_pos=None):
     """The same tile loop as ``tiled_emulation`` with the issue-interleaved kernel's max rule
     (tiny-flash-attention_amd/csrc/tfa_fwd_kernel_il.h): instead of the exact running max of
     main_torch_only.py:240-257 every row keeps a REFERENCE exponent ``ref`` (log2 domain).  A group of
@@ -200,7 +200,9 @@ def tiled_emulation_lazy(q, k, v, is_causal, softmax_scale, block_n=64, group=32
     acc = torch.zeros((B, H, Nq, D), dtype=torch.float32)
     l = torch.zeros((B, H, Nq, 1), dtype=torch.float32)
     ref = torch.full((B, H, Nq, 1), -1e30, dtype=torch.float32)
-    rows = torch.arange(Nq)[:, None] + ((Nk if nk_total is None else nk_total) - Nq)
+    # (row_pos: query positions of the rows when they are not 0..Nq-1 — GQA heads packed as rows, tfa_api.hip: pack_gqa_rows;
+    #  nk_total - len(positions' range) is then the caller's business: pass the shift through nk_total = Nk_total_of_the_original)
+    rows = (torch.arange(Nq)[:, None] + ((Nk if nk_total is None else nk_total) - Nq)) if row_pos is None else row_pos[:, None]
     pos = torch.arange(Nk) if key_pos is None else key_pos
     for kv_start in range(0, Nk, block_n):
         k_tile = kf[:, :, kv_start:kv_start + block_n, :]

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("args", [["--n", "200", "--seed", "7"], ["--n", "80", "--seed", "8", "--big"], ["--n", "150", "--seed", "11", "--decode"]])
+@pytest.mark.parametrize("args", [["--n", "200", "--seed", "7"], ["--n", "80", "--seed", "8", "--big"], ["--n", "150", "--seed", "11", "--decode"],
+                                  ["--n", "150", "--seed", "12", "--spec"]])
 def test_fuzz_forward_against_device_fp32(args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_fwd.py")] + args, capture_output=True, text=True, timeout=900)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-12:])

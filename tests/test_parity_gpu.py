@@ -70,12 +70,15 @@ def check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype, var=None):
     # problem (tfa_api.hip: pack_gqa_rows) — same math, but a wave's 32 rows (the unit that re-bases together) now span heads
     Bq, Hq, Nqq, Dq = q.shape
     G = Hq // k.shape[1]
-    packed = _lib.get_variant() < 0 and G > 1 and G * Nqq <= 128 and (Nqq == 1 or not causal)
-    qe, ce = (q.reshape(Bq, k.shape[1], G * Nqq, Dq), False) if packed else (q, causal)
+    Nkk = k.shape[2]
+    with_pos = Nqq > 1 and causal                       # packed rows keep their query position: row % Nq (+ the causal shift)
+    packed = _lib.get_variant() < 0 and G > 1 and G * Nqq <= 128 and (Nqq == 1 or not causal or (Dq <= 128 and Nkk >= Nqq))
+    qe, ce = (q.reshape(Bq, k.shape[1], G * Nqq, Dq), causal and with_pos) if packed else (q, causal)
+    kw = {"row_pos": torch.arange(G * Nqq) % Nqq + (Nkk - Nqq)} if (packed and with_pos) else {}
     if var in (KSPLIT, KSPLIT_PAIR):                    # two wave groups over the even / odd key tiles, merged
-        emu, lse_e = oracle.ksplit_emulation(qe, k, v, ce, sc, 64, return_lse=True)
+        emu, lse_e = oracle.ksplit_emulation(qe, k, v, ce, sc, 64, return_lse=True, **kw)
     else:
-        emu, lse_e = emulate(qe, k, v, ce, sc, 64, return_lse=True)
+        emu, lse_e = emulate(qe, k, v, ce, sc, 64, return_lse=True, **kw)
     if packed:
         emu, lse_e = emu.reshape(q.shape), lse_e.reshape(Bq, Hq, Nqq)
     exact, lse_x = oracle.exact64(q, k, v, causal, sc, return_lse=True)
@@ -728,7 +731,9 @@ def test_reference_entry_points_split_decode_shapes(tfa, oracle, dev, dtype, B, 
     (torch.bfloat16, 3, 32, 8, 1, 1500, 128, True),         # decode, G = 4: four query heads per K/V head become four rows
     (torch.float16, 2, 16, 1, 1, 700, 64, True),            # MQA: all 16 heads of a batch are one 16-row problem
     (torch.bfloat16, 2, 8, 2, 3, 600, 128, False),          # a few rows, non-causal: packed when the heads are adjacent (bhnd)
-    (torch.bfloat16, 2, 8, 2, 3, 600, 128, True),           # a few rows, causal: rows of different positions -> not packed
+    (torch.bfloat16, 2, 8, 2, 3, 600, 128, True),           # a few rows, causal: packed, each row keeps its query position
+    (torch.float16, 4, 32, 8, 8, 2500, 64, True),           # speculative decoding: 8 draft tokens, G = 4 -> 32 rows
+    (torch.bfloat16, 1, 16, 2, 13, 200, 96, True),          # G x Nq = 104 rows: positions wrap inside and across waves
     (torch.float16, 1, 64, 2, 4, 500, 96, False),           # G x Nq = 128: exactly one query block
     (torch.float16, 1, 64, 2, 5, 500, 64, False),           # G x Nq = 160: beyond one block -> not packed
 ])
@@ -756,7 +761,7 @@ def test_gqa_query_heads_packed_as_rows(tfa, oracle, dev, dtype, B, H, Hk, Nq, N
     _lib.check(_lib.lib().tfa_fwd_plan(C.byref(p), C.byref(g1), C.byref(blk), C.byref(lds)))
     G = H // Hk
     adjacent = layout == "bhnd"
-    expect_packed = G * Nq <= 128 and (Nq == 1 or (not causal and adjacent))
+    expect_packed = G * Nq <= 128 and (Nq == 1 or adjacent)      # (causal rows keep their positions: KArgs::row_mod)
     assert (g1.value * G == g0.value) == expect_packed, (g0.value, g1.value)
     back = (lambda t: t) if layout == "bhnd" else (lambda t: t.transpose(1, 2))
     o, o_ref = back(out).float().cpu(), back(ref_out).float().cpu()

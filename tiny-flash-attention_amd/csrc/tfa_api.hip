@@ -85,7 +85,7 @@ bool slice_bytes(int64_t n, int64_t row_stride, int d, int esize, bool windowed,
   return true;
 }
 
-int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
+int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant, int row_mod = 0) {
   if (!p) return TFA_ERR_NULL;
   if (!p->q || !p->k || !p->v || !p->out) return TFA_ERR_NULL;
   if (p->dtype != TFA_F16 && p->dtype != TFA_BF16) return TFA_ERR_DTYPE;
@@ -141,6 +141,7 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
   if (nbh * a->nwork >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
   a->nbh = (int)nbh;
   a->dbg = g_dbg_flags;
+  a->row_mod = row_mod;
   a->dv = p->D;
   return TFA_OK;
 }
@@ -150,14 +151,20 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant) {
 // streamed once per K/V head instead of once per query head and the grid shrinks G-fold.  One query row: any strides, and
 // a causal mask hides nothing from it (its position is the last key), so the packed problem is non-causal.  More rows: only
 // non-causal and with the heads of q / out adjacent in memory (rows of consecutive heads are then equidistant).  The LSE layout
-// (B,H,Nq) is the packed problem's (B,Hk,G*Nq) as it stands.  Returns false when *p is not such a problem.
-bool pack_gqa_rows(const tfa_fwd_params* p, tfa_fwd_params* o) {
+// (B,H,Nq) is the packed problem's (B,Hk,G*Nq) as it stands.  Causal with several rows (speculative decoding, the tail of a
+// chunked prefill): row r of the packed block is query position r % Nq, which the decode instantiations of the il kernels
+// understand (KArgs::row_mod, *row_mod here; causal_rows says whether the caller's kernel is one of them); nk_total carries
+// the causal shift of the ORIGINAL problem (Nk - Nq) past the larger row count.  Returns false when *p is not such a problem.
+bool pack_gqa_rows(const tfa_fwd_params* p, tfa_fwd_params* o, int* row_mod = nullptr, bool causal_rows = false) {
+  if (row_mod) *row_mod = 0;
   if (!p || p->Hk <= 0 || p->H <= p->Hk || p->H % p->Hk != 0 || p->Nq <= 0 || p->Nk <= 0) return false;
   if (p->kv_offset != 0 || p->nk_total != 0) return false;
   const int G = p->H / p->Hk;
   const bool one_row = p->Nq == 1;
-  const bool adjacent = !p->is_causal && p->q_stride[1] == (int64_t)p->Nq * p->q_stride[2] && p->o_stride[1] == (int64_t)p->Nq * p->o_stride[2];
+  const bool adjacent = p->q_stride[1] == (int64_t)p->Nq * p->q_stride[2] && p->o_stride[1] == (int64_t)p->Nq * p->o_stride[2];
+  const bool with_positions = !one_row && p->is_causal;
   if (!one_row && !adjacent) return false;
+  if (with_positions && !(causal_rows && row_mod && p->D <= 128 && p->Nk >= p->Nq)) return false;
   if ((long long)G * p->Nq > 128) return false;          // beyond one query block nothing is shared any more
   *o = *p;
   o->H = p->Hk;
@@ -167,6 +174,10 @@ bool pack_gqa_rows(const tfa_fwd_params* p, tfa_fwd_params* o) {
     o->o_stride[2] = p->o_stride[1];
     o->is_causal = 0;
   }
+  if (with_positions) {
+    *row_mod = p->Nq;
+    o->nk_total = (int64_t)p->Nk + (int64_t)(G - 1) * p->Nq;   // shift = nk_total - G*Nq = Nk - Nq
+  }
   o->q_stride[1] = (int64_t)G * p->q_stride[1];
   o->o_stride[1] = (int64_t)G * p->o_stride[1];
   return true;
@@ -174,10 +185,16 @@ bool pack_gqa_rows(const tfa_fwd_params* p, tfa_fwd_params* o) {
 
 int run(const tfa_fwd_params* p_in, void* stream, tfa::LaunchGeom* geom, bool dry) {
   tfa_fwd_params packed;
-  const tfa_fwd_params* p = (g_variant < 0 && !(g_dbg_flags & 4096) && pack_gqa_rows(p_in, &packed)) ? &packed : p_in;
-  const int variant = pick_variant(p);
+  int row_mod = 0;
+  const tfa_fwd_params* p = (g_variant < 0 && !(g_dbg_flags & 4096) && pack_gqa_rows(p_in, &packed, &row_mod, true)) ? &packed : p_in;
+  int variant = pick_variant(p);
   tfa::KArgs a;
-  const int st = validate(p, &a, variant);
+  int st = validate(p, &a, variant, row_mod);
+  if (st == TFA_OK && a.big && row_mod) {                 // (the windowed instantiations know nothing of packed positions)
+    p = p_in;
+    variant = pick_variant(p);
+    st = validate(p, &a, variant);
+  }
   if (st != TFA_OK) return st;
   const bool causal = p->is_causal != 0;
   const bool f32out = p->out_dtype == TFA_F32;
@@ -336,7 +353,8 @@ int tfa_fwd_variant(const tfa_fwd_params* p) {
   const int st = run(p, nullptr, &g, true);
   if (st != 0) return st > 0 ? TFA_ERR_SHAPE : st;
   tfa_fwd_params packed;                                  // (the problem run() actually dispatches: see pack_gqa_rows)
-  return pick_variant((g_variant < 0 && !(g_dbg_flags & 4096) && pack_gqa_rows(p, &packed)) ? &packed : p);
+  int row_mod = 0;
+  return pick_variant((g_variant < 0 && !(g_dbg_flags & 4096) && pack_gqa_rows(p, &packed, &row_mod, true)) ? &packed : p);
 }
 
 int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, float* avg_ms) {

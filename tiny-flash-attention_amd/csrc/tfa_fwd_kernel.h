@@ -59,6 +59,8 @@ struct KArgs {
                     // (< 2 GiB); the il kernels also exist in a WINDOWED instantiation (VF_IL_WINDOWED: rsrc_at, one query
                     // block / one K/V tile per descriptor) that tfa_api.hip launches when a slice is larger
   int big;          // some slice does not fit one descriptor: launch the windowed instantiation
+  int row_mod;      // > 0: GQA query heads packed as rows (tfa_api.hip: pack_gqa_rows) in a CAUSAL problem — row r of the block is
+                    // query position r % row_mod of one of the packed heads; 0: row r is position r
   float scale;      // softmax_scale
   float scale_log2; // softmax_scale * log2(e)
   int grid;         // workgroups launched (persistent kernels walk work items with this stride)

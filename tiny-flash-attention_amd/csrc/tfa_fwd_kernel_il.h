@@ -313,7 +313,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     const int q0x = mbx * BM;
     int kve = p.Nk;
     if (CAUSAL) {
-      const int lim = q0x + BM + shift;
+      const int lim = (((VF & VF_IL_IDLE) && p.row_mod > 0) ? p.row_mod : q0x + BM) + shift;
       kve = lim < kve ? lim : kve;
     }
     const int ntx = own_tiles(kve > 0 ? (kve + BN - 1) / BN : 0);
@@ -337,9 +337,12 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     const int mb = block_of(pass);
     if (p.trace && pass == 1 && tr_pass == 1) t_start = __builtin_amdgcn_s_memtime();
     const int q0 = mb * BM;
+    // query POSITIONS of the wave's rows (for the causal mask): rows themselves, or — packed GQA heads, decode instantiation
+    // only — row % row_mod, in which case a wave's rows span every position 0 .. row_mod-1
+    const int rmod = ((VF & VF_IL_IDLE) && CAUSAL) ? p.row_mod : 0;
     int kv_end = p.Nk;
     if (CAUSAL) {
-      const int lim = q0 + BM + shift;
+      const int lim = (rmod > 0 ? rmod : q0 + BM) + shift;
       kv_end = lim < kv_end ? lim : kv_end;
     }
     const int ntg = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;   // tiles of the head this block visits
@@ -350,7 +353,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 
     const int wave_row0 = q0 + wrow * 32;
     const int my_row = wave_row0 + qi;
-    const int last_g = CAUSAL ? ((wave_row0 + 31 + shift) >= 0 ? (wave_row0 + 31 + shift) / BN : -1) : (ntg - 1);   // last tile of the head the wave's rows see
+    const int pos_lo = rmod > 0 ? 0 : wave_row0, pos_hi = rmod > 0 ? rmod - 1 : wave_row0 + 31;   // positions of the wave's rows: [pos_lo, pos_hi]
+    const int my_pos = rmod > 0 ? my_row % rmod : my_row;
+    const int last_g = CAUSAL ? ((pos_hi + shift) >= 0 ? (pos_hi + shift) / BN : -1) : (ntg - 1);   // last tile of the head the wave's rows see
     const int wave_last_tile = KSPLIT ? (last_g >= grp ? (last_g - grp) >> 1 : -1) : last_g;
 
     float l4[4] = {0.f, 0.f, 0.f, 0.f};              // row sum of P, four interleaved partial sums carried across the tiles
@@ -374,12 +379,12 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     auto needs_mask = [&](int t) -> bool {
       const int key0 = key0_of(t);
       bool nm = (key0 + BN > p.Nk);
-      if (CAUSAL) nm = nm || (key0 + BN - 1 > wave_row0 + shift);
+      if (CAUSAL) nm = nm || (key0 + BN - 1 > pos_lo + shift);
       return nm;
     };
     auto apply_mask = [&](int t, f32x16 (&s)[2]) {
       int lim = p.Nk - 1;
-      if (CAUSAL) { const int c = my_row + shift; lim = c < lim ? c : lim; }
+      if (CAUSAL) { const int c = my_pos + shift; lim = c < lim ? c : lim; }
       lim -= key0_of(t) + 4 * hi;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       int first_g = 0x3fffffff;                            // first tile OF THE HEAD that needs a mask for this wave
       if (p.Nk % BN) first_g = p.Nk / BN;
       if (CAUSAL) {
-        const int c = wave_row0 + shift + 1;               // keys 0..c-1 are visible to every row of the wave
+        const int c = pos_lo + shift + 1;                  // keys 0..c-1 are visible to every row of the wave
         const int full = c > 0 ? c / BN : 0;               // tiles 0..full-1 need no mask
         first_g = full < first_g ? full : first_g;
       }

@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=300)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--decode", action="store_true", help="few query rows against long K/V through the reference-style path (auto_split: tfa_fwd_suggest_splits + tfa_fwd_splitkv)")
+ap.add_argument("--spec", action="store_true", help="GQA, a few causal query rows (speculative decoding): the packed-rows path with query positions")
 ap.add_argument("--big", action="store_true", help="more heads and batches, longer sequences: grids that fill the chip (il8, paired key-split)")
 a = ap.parse_args()
 rng = random.Random(a.seed)
@@ -41,12 +42,17 @@ for it in range(a.n):
         B, Hk = rng.choice([1, 1, 2]), rng.choice([1, 2, 4, 8]); H = Hk * rng.choice([1, 2, 4])
         Nq, Nk = rng.choice([1, 1, 2, 7, 16, 33, 128, 200]), rng.randint(4096, 40000)
         layout = "bhnd"
+    if a.spec:
+        D = rng.choice([64, 128, 96, 32, 72])
+        B, Hk = rng.choice([1, 2, 5]), rng.choice([1, 2, 4, 8]); H = Hk * rng.choice([2, 4, 8])
+        Nq, Nk = rng.choice([2, 3, 4, 5, 8, 13, 16, 31]), rng.randint(1, 6000)
+        causal = rng.random() < 0.8
     cap = 4e9 if a.big else 6e8
     if B * H * Nq * Nk > cap:
         Nk = max(1, int(cap / (B * H * Nq)))
-    layout = rng.choice(["bhnd", "bnhd"]) if not a.decode else "bhnd"
+    layout = rng.choice(["bhnd", "bnhd"]) if not (a.decode or a.spec) else "bhnd"
     shp = (lambda n, h: (B, h, n, D)) if layout == "bhnd" else (lambda n, h: (B, n, h, D))
-    pad = rng.choice([0, 0, 0, 8, 24, 64])               # row stride D + pad: rows that do not follow each other in memory
+    pad = 0 if a.spec else rng.choice([0, 0, 0, 8, 24, 64])               # row stride D + pad: rows that do not follow each other in memory
     def mk(n, h):
         full = torch.empty(shp(n, h)[:3] + (D + pad,), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(dt)
         return full[..., :D] if pad else full
