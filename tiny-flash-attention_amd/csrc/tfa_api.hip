@@ -41,7 +41,7 @@ int pick_variant(const tfa_fwd_params* p) {
   const long long blocks256 = (long long)p->B * p->H * ((p->Nq + 255) / 256);
   const long long blocks128 = (long long)p->B * p->H * ((p->Nq + 127) / 128);
   const int cus = num_cus();
-  const bool whole_seq = p->kv_offset == 0 && p->nk_total == 0;
+  const bool whole_seq = true;   // (partial passes — kv_offset / nk_total — reach the kernels as a causal shift only: every kernel takes them)
   // Grids of at most one 128-row block per CU: the 4-wave kernel would run one wave per SIMD (causal: paired, on half the CUs) —
   // split the keys inside the workgroup instead (il8-ksplit: 8 waves on one block, unpaired).  Non-causal it pays from 16 KV
   // tiles on (BASELINE config 2 +5 %, B1 H16 N2048 +9 %, B1 H8 N4096 +12 %; N=512 -4 %), causal always (B1 H8 N4096 +32 %,
