@@ -41,7 +41,7 @@ int pick_variant(const tfa_fwd_params* p) {
   const long long blocks256 = (long long)p->B * p->H * ((p->Nq + 255) / 256);
   const long long blocks128 = (long long)p->B * p->H * ((p->Nq + 127) / 128);
   const int cus = num_cus();
-  const bool whole_seq = true;   // (partial passes — kv_offset / nk_total — reach the kernels as a causal shift only: every kernel takes them)
+  // (partial passes — kv_offset / nk_total — reach the kernels as a causal shift only: every rule below applies to them too)
   // Grids of at most one 128-row block per CU: the 4-wave kernel would run one wave per SIMD (causal: paired, on half the CUs) —
   // split the keys inside the workgroup instead (il8-ksplit: 8 waves on one block, unpaired).  Non-causal it pays from 16 KV
   // tiles on (BASELINE config 2 +5 %, B1 H16 N2048 +9 %, B1 H8 N4096 +12 %; N=512 -4 %), causal always (B1 H8 N4096 +32 %,
@@ -50,10 +50,10 @@ int pick_variant(const tfa_fwd_params* p) {
   const auto small = [&](int64_t n, const int64_t* st, int es) { return ((n + 512) * st[2] + p->D) * es < (int64_t)0x7fffffff; };
   const bool one_descriptor = small(p->Nq, p->q_stride, 2) && small(p->Nk, p->k_stride, 2) && small(p->Nk, p->v_stride, 2) &&
                               small(p->Nq, p->o_stride, 4);   // (slices of 2 GiB and more: the windowed il4 / il8 instantiations)
-  if (whole_seq && one_descriptor && blocks128 <= cus && p->Nk >= (p->is_causal ? 512 : 1024)) return tfa::kKSplitVariant;
+  if (one_descriptor && blocks128 <= cus && p->Nk >= (p->is_causal ? 512 : 1024)) return tfa::kKSplitVariant;
   // causal, up to two 128-row blocks per CU, long sequences: the same kernel with the blocks paired heavy+light (one round of
   // equal workgroups, two waves per SIMD): B1 H16 N4096 +4 %, B1 H8 N8192 +7 %, B1 H4 N16384 +11 % over il4; N=2048: -2..+5 %
-  if (whole_seq && one_descriptor && p->is_causal && blocks128 <= 2 * cus && p->Nk >= 4096) return tfa::kKSplitPairVariant;
+  if (one_descriptor && p->is_causal && blocks128 <= 2 * cus && p->Nk >= 4096) return tfa::kKSplitPairVariant;
   // at most 128 query rows (decode, cross-attention onto few queries): a 256-row block would be half idle; 128-row blocks put two
   // workgroups on a CU and keep twice the K/V bytes in flight (B32 H32 Nq1 Nk16384 D64: K/V at 6.1 vs 5.0 TB/s, D128: 6.1 vs 6.0)
   if (p->Nq <= 128) return tfa::kSmallGridVariant;
