@@ -154,6 +154,23 @@ def test_suggested_split_count():
     assert sug(B=1, H=8, Hk=8, Nq=1, Nk=16384, D=256) == 1       # the split-KV kernel stops at D = 128
 
 
+def test_gqa_decode_is_planned_per_kv_head():
+    # one query row, H/Hk = 4 query heads per K/V head: the library runs them as four rows of one problem (pack_gqa_rows) —
+    # one workgroup per (batch, K/V head) instead of one per query head; a few causal rows likewise when the heads are adjacent
+    def grid(**kw):
+        p = _params(**kw)
+        return plan(p)[1]
+    assert grid(B=64, H=32, Hk=8, Nq=1, Nk=8192) == 64 * 8
+    assert grid(B=64, H=32, Hk=32, Nq=1, Nk=8192) == 64 * 32
+    assert grid(B=64, H=32, Hk=8, Nq=4, Nk=8192) == 64 * 8            # causal draft rows keep their positions (KArgs::row_mod)
+    assert grid(B=64, H=32, Hk=8, Nq=64, Nk=8192) == 64 * 32           # 4 x 64 rows exceed one 128-row block: not packed
+    _lib.set_variant(32)
+    try:
+        assert grid(B=64, H=32, Hk=8, Nq=1, Nk=8192) == 64 * 32       # a forced kernel variant runs the problem as given
+    finally:
+        _lib.set_variant(-1)
+
+
 def test_f32_out_and_gqa_accepted():
     assert plan(_params(out_dtype=_lib.TFA_F32))[0] == 0   # fp32 debug output
     assert plan(_params(H=8, Hk=2))[0] == 0
