@@ -11,14 +11,6 @@
 #include "tfa.h"
 #include "tfa_launch.h"
 
-namespace tfa {
-// defined in tfa_fwd_inst_<dtype>_<D>.hip
-template <> hipError_t launch_fwd<__bf16, 64>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
-template <> hipError_t launch_fwd<__bf16, 128>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
-template <> hipError_t launch_fwd<_Float16, 64>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
-template <> hipError_t launch_fwd<_Float16, 128>(const KArgs&, bool, bool, int, hipStream_t, LaunchGeom*, bool);
-}  // namespace tfa
-
 namespace {
 
 // Debug knobs (tfa_set_variant, tfa_debug_set_trace) are PER THREAD: a thread that forces a variant or a trace buffer

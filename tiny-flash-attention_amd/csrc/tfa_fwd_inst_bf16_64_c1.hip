@@ -1,0 +1,5 @@
+// one instantiation unit: dtype=bf16 head_dim=64 causal=1
+#define TFA_T __bf16
+#define TFA_D 64
+#define TFA_CAUSAL true
+#include "tfa_fwd_inst.inc"

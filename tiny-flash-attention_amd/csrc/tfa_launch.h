@@ -79,8 +79,18 @@ struct LaunchGeom {
   int grid, block, lds;
 };
 
+// one translation unit per (dtype, width, causal): tfa_fwd_inst_<dtype>_<D>_c<0|1>.hip specialises launch_fwd_c
+template <typename T, int D, bool CAUSAL>
+hipError_t launch_fwd_c(const KArgs& a, bool f32out, int variant, hipStream_t stream, LaunchGeom* geom, bool dry);
+#define TFA_FWD_UNITS(T, D)                                                                             \
+  template <> hipError_t launch_fwd_c<T, D, false>(const KArgs&, bool, int, hipStream_t, LaunchGeom*, bool); \
+  template <> hipError_t launch_fwd_c<T, D, true>(const KArgs&, bool, int, hipStream_t, LaunchGeom*, bool);
+TFA_FWD_UNITS(__bf16, 64) TFA_FWD_UNITS(__bf16, 128) TFA_FWD_UNITS(_Float16, 64) TFA_FWD_UNITS(_Float16, 128)
+#undef TFA_FWD_UNITS
 template <typename T, int D>
-hipError_t launch_fwd(const KArgs& a, bool causal, bool f32out, int variant, hipStream_t stream, LaunchGeom* geom, bool dry);
+static inline hipError_t launch_fwd(const KArgs& a, bool causal, bool f32out, int variant, hipStream_t stream, LaunchGeom* geom, bool dry) {
+  return causal ? launch_fwd_c<T, D, true>(a, f32out, variant, stream, geom, dry) : launch_fwd_c<T, D, false>(a, f32out, variant, stream, geom, dry);
+}
 
 // variants compiled into this build
 static inline bool variant_built(int variant) {

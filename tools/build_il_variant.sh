@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage: [UNITS="bf16_128 f16_64"] tools/build_il_variant.sh NAME "-DTFA_IL_...=..." : lib_NAME/libtfa_hip.so = product objects + the listed
+# usage: [UNITS="bf16_128_c1 f16_64_c0"] tools/build_il_variant.sh NAME "-DTFA_IL_...=..." : lib_NAME/libtfa_hip.so = product objects + the listed
 # il units (default bf16_128) rebuilt with the given flags (for tools/ab_multi.py name=path:30).
 set -e
 cd "$(dirname "$0")/../tiny-flash-attention_amd/csrc"
-NAME=$1; FLAGS=$2; UNITS=${UNITS:-bf16_128}
+NAME=$1; FLAGS=$2; UNITS=${UNITS:-"bf16_128_c0 bf16_128_c1"}
 mkdir -p ../build_$NAME ../lib_$NAME
 objs=$(ls ../build/*.o)
 for u in $UNITS; do
