@@ -122,3 +122,29 @@ def test_tiled_emulation_general_shapes(oracle):
         # with P left in fp32 the two formulations coincide to fp32 round-off
         e32 = oracle.tiled_emulation(q, k, v, causal, 0.125, p_dtype=torch.float32)
         assert (e32 - oracle.exact64(q, k, v, causal, 0.125)).abs().max().item() < 5e-6
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_kernel_emulations_stay_on_the_exact_result(oracle, causal):
+    """The emulations of the kernels' own rounding points (lazy re-base, key-split wave groups, GQA heads packed as rows with
+    their query positions) are restatements of the same function: they must sit on exact64 within the P-rounding bound."""
+    q, k, v = oracle.make_inputs(1, 4, 70, 64, torch.bfloat16, seed=9, Hk=2, Nk=333)
+    sc = 0.125
+    exact, lse_x = oracle.exact64(q, k, v, causal, sc, return_lse=True)
+    A = oracle.abs_weighted(q, k, v, causal, sc)
+    bound = 2.0 ** -8 * A + 1e-6
+    for name, fn in (("lazy", lambda: oracle.tiled_emulation_lazy(q, k, v, causal, sc, 64, return_lse=True)),
+                     ("ksplit", lambda: oracle.ksplit_emulation(q, k, v, causal, sc, 64, return_lse=True))):
+        o, l = fn()
+        assert bool(((o - exact).abs() <= bound).all()), name
+        fin = torch.isfinite(lse_x)
+        assert bool((torch.isinf(l) == ~fin).all()) and (l[fin] - lse_x[fin]).abs().max().item() <= 1e-4, name
+    # GQA heads packed as rows: (B, Hk, G*Nq, D) with row position r % Nq (+ the causal shift Nk - Nq)
+    q2, k2, v2 = oracle.make_inputs(2, 8, 5, 64, torch.float16, seed=10, Hk=2, Nk=200)
+    ex2, lx2 = oracle.exact64(q2, k2, v2, causal, sc, return_lse=True)
+    A2 = oracle.abs_weighted(q2, k2, v2, causal, sc)
+    qp = q2.reshape(2, 2, 20, 64)
+    kw = {"row_pos": torch.arange(20) % 5 + (200 - 5)} if causal else {}
+    o2, l2 = oracle.tiled_emulation_lazy(qp, k2, v2, causal, sc, 64, return_lse=True, **kw)
+    assert bool(((o2.reshape(ex2.shape) - ex2).abs() <= 2.0 ** -11 * A2 + 1e-6).all())
+    assert (l2.reshape(lx2.shape) - lx2).abs().max().item() <= 1e-4
