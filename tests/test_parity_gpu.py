@@ -734,6 +734,7 @@ def test_reference_entry_points_split_decode_shapes(tfa, oracle, dev, dtype, B, 
     (torch.bfloat16, 2, 8, 2, 3, 600, 128, True),           # a few rows, causal: packed, each row keeps its query position
     (torch.float16, 4, 32, 8, 8, 2500, 64, True),           # speculative decoding: 8 draft tokens, G = 4 -> 32 rows
     (torch.bfloat16, 1, 16, 2, 13, 200, 96, True),          # G x Nq = 104 rows: positions wrap inside and across waves
+    (torch.float16, 40, 32, 8, 4, 4200, 64, True),          # 320 packed blocks, long keys: the paired key-split kernel's decode form
     (torch.float16, 1, 64, 2, 4, 500, 96, False),           # G x Nq = 128: exactly one query block
     (torch.float16, 1, 64, 2, 5, 500, 64, False),           # G x Nq = 160: beyond one block -> not packed
 ])

@@ -46,6 +46,10 @@ constexpr int VF_IL_KSPLIT = 1 << 25;    // small non-causal grids: the 8 waves 
                                          // to group 0 through LDS at the end.  Two waves per SIMD where 128-row workgroups alone would leave one.
 constexpr int VF_IL_IDLE = 1 << 26;      // waves whose 32 rows all lie behind the last query row skip the tile work (decode-like problems: one
                                          // query block with one valid wave).  Its own instantiation: the flag costs the causal headline 0.5 %
+#ifndef TFA_IL_DECODE_NT
+#define TFA_IL_DECODE_NT 1               // decode instantiations (VF_IL_IDLE: one query block per head): K/V tiles nobody else reads are
+                                         // loaded non-temporal — MHA decode 6.3 -> 6.6 TB/s, packed GQA 5.9 -> 7.0 TB/s (profiles/r02_decode_nt_ab.txt)
+#endif
 constexpr int VF_IL_WINDOWED = 1 << 24;  // K/V tiles through per-tile descriptors (rsrc_at): a (b,h) slice may exceed 2 GiB.  ~6 % slower (a fresh
                                          // descriptor per tile: ~14 SALU + the SGPR->VMEM wait states), so only launched when needed
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
@@ -267,12 +271,15 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const int k_tile_stride = (KSPLIT ? 2 : 1) * BN * (int)p.ks_n * 2;
   const int v_tile_stride = (KSPLIT ? 2 : 1) * BN * (int)p.vs_n * 2;
 
+  const bool kv_private = p.H == p.Hk;             // (query heads that share a K/V head share its tiles in L2: no streaming hint then)
   auto dma_k1 = [&](int t, int buf, int i) {
     if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(kbase, k_bytes, (unsigned long long)t * (unsigned)k_tile_stride), lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i]);
+    else if ((VF & VF_IL_IDLE) && TFA_IL_DECODE_NT && kv_private) lds_dma16_m0_nt(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
     else lds_dma16_m0(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
   };
   auto dma_v1 = [&](int t, int buf, int i) {
     if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(vbase, v_bytes, (unsigned long long)t * (unsigned)v_tile_stride), lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i]);
+    else if ((VF & VF_IL_IDLE) && TFA_IL_DECODE_NT && kv_private) lds_dma16_m0_nt(v_rs, lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i] + t * v_tile_stride);
     else lds_dma16_m0(v_rs, lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i] + t * v_tile_stride);
   };
   auto dma_k = [&](int t, int buf) {

@@ -44,8 +44,8 @@ for it in range(a.n):
         layout = "bhnd"
     if a.spec:
         D = rng.choice([64, 128, 96, 32, 72])
-        B, Hk = rng.choice([1, 2, 5]), rng.choice([1, 2, 4, 8]); H = Hk * rng.choice([2, 4, 8])
-        Nq, Nk = rng.choice([2, 3, 4, 5, 8, 13, 16, 31]), rng.randint(1, 6000)
+        B, Hk = rng.choice([1, 2, 5, 40, 70]), rng.choice([1, 2, 4, 8]); H = Hk * rng.choice([2, 4, 8])     # (large batches: grids beyond one block per CU)
+        Nq, Nk = rng.choice([2, 3, 4, 5, 8, 13, 16, 31]), rng.randint(1, 6000 if B < 40 else 5000)
         causal = rng.random() < 0.8
     cap = 4e9 if a.big else 6e8
     if B * H * Nq * Nk > cap:
