@@ -21,6 +21,16 @@ thread_local int g_dbg_flags = 0;                    // kernel bring-up flags (t
 
 int num_cus() { return tfa::num_cus_current_device(); }
 
+// every (b,h) slice of q, k, v and out fits ONE buffer descriptor (< 2 GiB including the rows a ragged block may reach past the
+// end): what the key-split, split-KV, backward and x4 kernels need; larger slices run the windowed il4 / il8 instantiations
+bool one_descriptor(const tfa_fwd_params* p) {
+  const auto small = [&](int64_t n, const int64_t* st, int es) { return ((n + 512) * st[2] + p->D) * es < (int64_t)0x7fffffff; };
+  return small(p->Nq, p->q_stride, 2) && small(p->Nk, p->k_stride, 2) && small(p->Nk, p->v_stride, 2) && small(p->Nq, p->o_stride, 4);
+}
+
+// NOTE on tfa_set_variant (a per-thread debug knob): a forced variant means "run exactly that kernel on the problem as given" —
+// GQA row packing (pack_gqa_rows) and tfa_fwd_suggest_splits are both switched off while one is set, and head dims above 128
+// always run kX4D256Variant (the only kernel that wide).  Tools that force a variant reset it to -1 in a finally block.
 int pick_variant(const tfa_fwd_params* p) {
   if (p && p->D > 128) return tfa::kX4D256Variant;   // one kernel serves 136..256 (a forced variant does not apply)
   if (g_variant >= 0) return g_variant;
@@ -39,13 +49,11 @@ int pick_variant(const tfa_fwd_params* p) {
   // tiles on (BASELINE config 2 +5 %, B1 H16 N2048 +9 %, B1 H8 N4096 +12 %; N=512 -4 %), causal always (B1 H8 N4096 +32 %,
   // B1 H16 N2048 +32 %, B1 H64 N512 +32 %); with two blocks per CU it is mixed (-20 .. +10 %) and not used
   // (profiles/r02_ksplit_ab.txt).
-  const auto small = [&](int64_t n, const int64_t* st, int es) { return ((n + 512) * st[2] + p->D) * es < (int64_t)0x7fffffff; };
-  const bool one_descriptor = small(p->Nq, p->q_stride, 2) && small(p->Nk, p->k_stride, 2) && small(p->Nk, p->v_stride, 2) &&
-                              small(p->Nq, p->o_stride, 4);   // (slices of 2 GiB and more: the windowed il4 / il8 instantiations)
-  if (one_descriptor && blocks128 <= cus && p->Nk >= (p->is_causal ? 512 : 1024)) return tfa::kKSplitVariant;
+  const bool one_desc = one_descriptor(p);   // (slices of 2 GiB and more: the windowed il4 / il8 instantiations)
+  if (one_desc && blocks128 <= cus && p->Nk >= (p->is_causal ? 512 : 1024)) return tfa::kKSplitVariant;
   // causal, up to two 128-row blocks per CU, long sequences: the same kernel with the blocks paired heavy+light (one round of
   // equal workgroups, two waves per SIMD): B1 H16 N4096 +4 %, B1 H8 N8192 +7 %, B1 H4 N16384 +11 % over il4; N=2048: -2..+5 %
-  if (one_descriptor && p->is_causal && blocks128 <= 2 * cus && p->Nk >= 4096) return tfa::kKSplitPairVariant;
+  if (one_desc && p->is_causal && blocks128 <= 2 * cus && p->Nk >= 4096) return tfa::kKSplitPairVariant;
   // at most 128 query rows (decode, cross-attention onto few queries): a 256-row block would be half idle; 128-row blocks put two
   // workgroups on a CU and keep twice the K/V bytes in flight (B32 H32 Nq1 Nk16384 D64: K/V at 6.1 vs 5.0 TB/s, D128: 6.1 vs 6.0)
   if (p->Nq <= 128) return tfa::kSmallGridVariant;
@@ -175,19 +183,24 @@ bool pack_gqa_rows(const tfa_fwd_params* p, tfa_fwd_params* o, int* row_mod = nu
   return true;
 }
 
-int run(const tfa_fwd_params* p_in, void* stream, tfa::LaunchGeom* geom, bool dry) {
+int run(const tfa_fwd_params* p_in, void* stream, tfa::LaunchGeom* geom, bool dry, int* variant_out = nullptr) {
   tfa_fwd_params packed;
   int row_mod = 0;
   const tfa_fwd_params* p = (g_variant < 0 && !(g_dbg_flags & 4096) && pack_gqa_rows(p_in, &packed, &row_mod, true)) ? &packed : p_in;
   int variant = pick_variant(p);
   tfa::KArgs a;
   int st = validate(p, &a, variant, row_mod);
-  if (st == TFA_OK && a.big && row_mod) {                 // (the windowed instantiations know nothing of packed positions)
+  // The packed description is an optimisation, never a requirement: whenever it does not validate (packing moves the head
+  // stride into the row-stride slot, so e.g. a q broadcast over heads — head stride 0 — fails the "rows do not overlap" test)
+  // or needs the windowed instantiations (which know nothing of packed positions), the problem runs as the caller gave it.
+  if (p != p_in && (st != TFA_OK || (a.big && row_mod))) {
     p = p_in;
+    row_mod = 0;
     variant = pick_variant(p);
     st = validate(p, &a, variant);
   }
   if (st != TFA_OK) return st;
+  if (variant_out) *variant_out = variant;
   const bool causal = p->is_causal != 0;
   const bool f32out = p->out_dtype == TFA_F32;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -330,6 +343,9 @@ int tfa_fwd_suggest_splits(const tfa_fwd_params* p_in) {
   tfa_fwd_params packed;
   const tfa_fwd_params* p = pack_gqa_rows(p_in, &packed) ? &packed : p_in;
   if (p->D > 128 || p->kv_offset != 0 || p->nk_total != 0 || p->B <= 0 || p->H <= 0 || p->Nq <= 0) return 1;
+  // tfa_fwd_splitkv runs the one-descriptor-per-slice LDS-DMA kernel: a K/V cache whose (b,h) slice spans 2 GiB or more (long
+  // strided caches) stays on tfa_fwd, whose il kernels address it through windows
+  if (!one_descriptor(p)) return 1;
   const long long blocks = (long long)p->B * p->H * ((p->Nq + 127) / 128);
   const int cus = num_cus();
   if (blocks * 4 > cus || p->Nk < 4096) return 1;
@@ -342,11 +358,10 @@ int tfa_fwd_suggest_splits(const tfa_fwd_params* p_in) {
 
 int tfa_fwd_variant(const tfa_fwd_params* p) {
   tfa::LaunchGeom g = {0, 0, 0};
-  const int st = run(p, nullptr, &g, true);
+  int variant = -1;                                       // run()'s final choice (after GQA packing and its fall-back)
+  const int st = run(p, nullptr, &g, true, &variant);
   if (st != 0) return st > 0 ? TFA_ERR_SHAPE : st;
-  tfa_fwd_params packed;                                  // (the problem run() actually dispatches: see pack_gqa_rows)
-  int row_mod = 0;
-  return pick_variant((g_variant < 0 && !(g_dbg_flags & 4096) && pack_gqa_rows(p, &packed, &row_mod, true)) ? &packed : p);
+  return variant;
 }
 
 int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, float* avg_ms) {
@@ -377,7 +392,11 @@ int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, f
 }
 
 int tfa_set_variant(int variant) {
-  if (variant < -1 || (variant >= tfa::kNumVariants && (variant < 100 || variant >= 2256 || (variant >= 716 && variant < 1000) || (variant >= 612 && variant < 700))) && !(variant >= 3000 && variant < 3256)) return TFA_ERR_VARIANT;
+  // dispatchable numbers: -1 (automatic), the kVariants table, and the timing-only ablation ranges of the EXPERIMENTAL build
+  const bool in_table = variant >= 0 && variant < tfa::kNumVariants;
+  const bool ablation = (variant >= 100 && variant < 612) || (variant >= 700 && variant < 716) || (variant >= 1000 && variant < 2256) ||
+                        (variant >= 3000 && variant < 3256);
+  if (variant != -1 && !in_table && !ablation) return TFA_ERR_VARIANT;
   if (variant >= 0 && variant < tfa::kNumVariants && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
   g_variant = variant;
   return TFA_OK;

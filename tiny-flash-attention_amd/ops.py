@@ -89,7 +89,10 @@ def flash_attn_fwd(q, k, v, is_causal=False, softmax_scale=None, *, layout="bhnd
     p.kv_offset = int(kv_offset)                     # split-KV: k, v are keys [kv_offset, kv_offset+Nk) of nk_total
     p.nk_total = 0 if nk_total is None else int(nk_total)
     L = _lib.lib()
-    splits = L.tfa_fwd_suggest_splits(C.byref(p)) if (auto_split and layout == "bhnd" and out.is_contiguous()) else 1
+    # tfa_fwd_splitkv's merge writes a dense (B,H,Nq,D) result: gate on the exact strides it checks (is_contiguous() ignores the
+    # strides of size-1 dims, and Nq == 1 is the very shape auto-split targets)
+    dense_out = (out.stride(3) == 1 and out.stride(2) == D and out.stride(1) == Nq * D and out.stride(0) == H * Nq * D)
+    splits = L.tfa_fwd_suggest_splits(C.byref(p)) if (auto_split and layout == "bhnd" and dense_out) else 1
     with torch.cuda.device(q.device):
         stream = torch.cuda.current_stream().cuda_stream
         if splits > 1:
