@@ -102,8 +102,55 @@ class Smi:
         return pw, clk, ex
 
 
+def run_cmd(cmd, out):
+    """--cmd mode: run a command that prints ARM_BEGIN <tag> / ARM_END <tag> lines; report power and clock per arm"""
+    import subprocess
+    smi = Smi()
+    print(f"smi interface: {smi.kind}  power cap: {smi.cap_w()} W", flush=True)
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            pw, clk, ex = smi.sample()
+            samples.append((time.perf_counter(), pw, clk, ex))
+            time.sleep(0.002)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    arms, cur, lines = [], None, []
+    pr = subprocess.Popen(cmd, shell=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, bufsize=1)
+    for line in pr.stdout:
+        t = time.perf_counter()
+        line = line.rstrip()
+        if line.startswith("ARM_BEGIN"):
+            cur = (line[len("ARM_BEGIN"):].strip(), t)
+        elif line.startswith("ARM_END") and cur:
+            arms.append((cur[0], cur[1], t, line[len("ARM_END"):].strip()))
+            cur = None
+        else:
+            print(line, flush=True)
+    pr.wait()
+    stop.set()
+    th.join()
+    for tag, t0, t1, text in arms:
+        mine = [x for x in samples if t0 + 0.5 <= x[0] <= t1]
+        pw = sorted(x[1] for x in mine if x[1] is not None)
+        ck = [x[2] for x in mine if x[2] is not None]
+        ppt = [x[3].get("ppt_residency_acc") for x in mine if "ppt_residency_acc" in x[3]]
+        acc = [x[3].get("accumulation_counter") for x in mine if "accumulation_counter" in x[3]]
+        res = f"{ppt[-1] - ppt[0]}/{acc[-1] - acc[0]}" if len(ppt) > 1 and len(acc) > 1 else "n/a"
+        line = (f"{text}  | power mean {(sum(pw) / len(pw)) if pw else float('nan'):6.1f} W max {pw[-1] if pw else float('nan'):6.1f} W (cap {smi.cap_w()} W)"
+                f"  gfxclk mean {(sum(ck) / len(ck)) if ck else float('nan'):6.0f} MHz  PPT-limited firmware samples {res}")
+        print(line, flush=True)
+        lines.append(line)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out.replace(".csv", ".txt"), "w") as f:
+        f.write(f"command: {cmd}\nsmi interface: {smi.kind}  power cap: {smi.cap_w()} W\n" + "\n".join(lines) + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--cmd", default="", help="sample while this shell command runs (it prints ARM_BEGIN/ARM_END lines) instead of the attention kernel")
     ap.add_argument("--cfg", default="cfg3")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--idle", type=float, default=1.0, help="idle seconds sampled between data sets")
@@ -111,6 +158,8 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_power_trace.csv"))
     a = ap.parse_args()
+    if a.cmd:
+        return run_cmd(a.cmd, a.out)
     dev = torch.device("cuda:0")
     L = _lib.lib()
     smi = Smi()
