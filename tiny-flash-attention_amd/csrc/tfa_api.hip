@@ -133,6 +133,7 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant, int row_mod = 
   a->scale = p->softmax_scale;
   a->trace = g_trace;
   a->grid = num_cus();
+  if (g_dbg_flags & 512) a->grid = 8;            // tests: persistent kernels with 8 workgroups, so that small problems walk several work items each
   a->scale_log2 = p->softmax_scale * 1.4426950408889634f;
   const int bm = ablate ? 256 : tfa::block_m_of(variant);
   a->nmb = (p->Nq + bm - 1) / bm;
