@@ -28,7 +28,9 @@ Protocol (what happens, in order; all of it is reported in the JSON line):
   5. K steps in the reference's own harness style: host timer, synchronize after EVERY call
      (flash_attention_cutlass/test.py:30-40) -> `reference_harness_ms`.
   6. one traced launch -> sustained shader clock.
-  7. rank 0, N=1: the reference's CPU paths on the host cores (`cpu_baseline`: the C path on a bounded
+  7. rank 0, N=1, forward mode: `secondary` — <= 8 s of driver-timed twins of the other numbers quoted in DESIGN.md: BASELINE
+     configs 2 and 4, the headline shape non-causal, one GQA decode shape (HBM-bound) and the headline backward.
+  8. rank 0, N=1: the reference's CPU paths on the host cores (`cpu_baseline`: the C path on a bounded
      sample of the same workload; `cpu_baseline_python`: the pure-Python path on its own config 1).
 
 Rank 0 prints ONE JSON line.  `value` = algorithmic flops of all ranks / wall time of the K
@@ -54,6 +56,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_BF16 = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+MFMA_ONLY_RANDOM_TFLOPS = 1710.0   # measured: a pure v_mfma_f32_32x32x16_bf16 stream on normal(0,0.5) operands, 1.70-1.72 PF at ~1.7 GHz
 
 CONFIGS = {
     # name: (B, H, N, D, dtype, causal)  — BASELINE.json configs 2..5 (per-GPU shapes)
@@ -129,6 +132,77 @@ def cpu_baseline_python(reps=3):
     }
 
 
+def secondary_measurements(dev, budget_s=8.0):
+    """Driver-timed twins of the builder-run numbers: after the headline's timed region, <= budget_s in
+    total, the other BASELINE configs, one decode shape and the headline backward — each: 0.25 s of untimed launches, then
+    one HIP-event pair around as many launches as fit its share of the budget.  `frac` = fraction of the 2.5 PF bf16 MFMA
+    peak, `hbm_frac` = algorithmic bytes / time against 8 TB/s (the bound of the decode shape)."""
+    from tiny_flash_attention_amd import _lib, ops
+
+    L = _lib.lib()
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    cases = [
+        ("cfg2", "fwd", (4, 8, 8, 1024, 1024, 64, torch.float16, False)),
+        ("cfg3nc", "fwd", (4, 32, 32, 4096, 4096, 128, torch.bfloat16, False)),
+        ("cfg4", "fwd", (1, 16, 16, 16384, 16384, 128, torch.bfloat16, False)),
+        ("decode_B64_H32_Hk8_Nq1_Nk8192", "fwd", (64, 32, 8, 1, 8192, 128, torch.bfloat16, True)),
+        ("cfg3_bwd", "bwd", (4, 32, 32, 4096, 4096, 128, torch.bfloat16, True)),
+    ]
+    share = budget_s / len(cases)
+    res = {}
+    for name, mode, (B, H, Hk, Nq, Nk, D, dt, causal) in cases:
+        try:
+            mk = lambda h, n: torch.empty((B, h, n, D), dtype=torch.float32, device=dev).normal_(0.0, 0.5).to(dt)
+            q, k, v = mk(H, Nq), mk(Hk, Nk), mk(Hk, Nk)
+            sc = 1.0 / math.sqrt(D)
+            out = torch.empty_like(q)
+            lse = torch.empty((B, H, Nq), dtype=torch.float32, device=dev)
+            p = ops.make_params(q, k, v, out, lse, causal, sc)
+            fl, by = C.c_double(), C.c_double()
+            if mode == "bwd":
+                _lib.check(L.tfa_fwd(C.byref(p), sptr))
+                dout = mk(H, Nq)
+                dq, dk, dv, delta = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty_like(lse)
+                pb = ops.make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, causal, sc)
+                call = lambda: _lib.check(L.tfa_bwd(C.byref(pb), sptr))
+                L.tfa_bwd_work(C.byref(pb), C.byref(fl), C.byref(by))
+            else:
+                call = lambda: _lib.check(L.tfa_fwd(C.byref(p), sptr))
+                L.tfa_fwd_work(C.byref(p), C.byref(fl), C.byref(by))
+            call()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_warm = 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            while time.perf_counter() - t0 < 0.25:          # untimed: clocks settle on this shape; also sizes the timed batch
+                e0.record(stream)
+                for _ in range(10):
+                    call()
+                e1.record(stream)
+                e1.synchronize()
+                n_warm += 10
+            per = max(e0.elapsed_time(e1) / 10.0, 1e-3)     # ms per launch, roughly
+            n = int(max(10, min(2000, (share - 0.35) * 1e3 / per)))
+            e0.record(stream)
+            for _ in range(n):
+                call()
+            e1.record(stream)
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            tfs = fl.value / (ms * 1e-3) / 1e12
+            gbs = by.value / (ms * 1e-3) / 1e9
+            res[name] = {"shape": f"B{B} H{H} Hk{Hk} Nq{Nq} Nk{Nk} D{D} {'bf16' if dt == torch.bfloat16 else 'fp16'} {'causal' if causal else 'full'}",
+                         "mode": mode, "ms": ms, "launches": n, "tflops": tfs, "frac": tfs / PEAK_TFLOPS_BF16,
+                         "algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
+                         "bound": "hbm" if name.startswith("decode") else "mfma",
+                         "kernel_variant": _lib.variant_name(L.tfa_fwd_variant(C.byref(p))) if mode == "fwd" else "bwd (delta + dQ + dK + dV launches)"}
+            del q, k, v, out, lse
+        except Exception as e:   # a report, never a reason to lose the headline line
+            res[name] = {"error": repr(e)}
+    return res
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -158,6 +232,7 @@ def main():
     ap.add_argument("--precondition-s", type=float, default=2.0,
                     help="untimed, disclosed clock/power pre-conditioning before the warm-up steps (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other configs, decode, backward: ~8 s)")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "bwd"],
                     help="fwd (default, the BASELINE metric) or bwd: a step is one tfa_bwd call")
     args = ap.parse_args()
@@ -353,7 +428,8 @@ def main():
             traffic = None
         tf = lambda ms: flops_step_rank / (ms * 1e-3) / 1e12
         line = {
-            "metric": ("bwd TFLOPS (2.5 x fwd flops)" if bwd else "fwd TFLOPS") + " + achieved %MFMA-roofline, (B=4,H=32,N=4096,D=128) bf16",
+            "metric": ("bwd TFLOPS (2.5 x fwd flops)" if bwd else "fwd TFLOPS") + f" + achieved %MFMA-roofline, (B={B},H={H},N={N},D={D}) "
+                      + ("bf16" if dtype == torch.bfloat16 else "fp16"),
             "value": value,
             "unit": "TFLOP/s",
             "n_gpus": world,
@@ -394,10 +470,16 @@ def main():
                 "sustained_clock_mhz": clk_mhz,
                 "peak_at_sustained_clock": (PEAK_TFLOPS_BF16 * clk_mhz / 2400.0) if clk_mhz else None,
                 "frac_at_sustained_clock": (achieved / (PEAK_TFLOPS_BF16 * clk_mhz / 2400.0)) if clk_mhz else None,
+                # what nothing-but-MFMA sustains on normal(0,0.5) operands under this board's 1400 W cap (tools/probe_mfma_power.hip,
+                # profiles/r03_mfma_power_ceiling.txt): reported beside the nominal peak, never instead of it
+                "mfma_only_ceiling_random_data": MFMA_ONLY_RANDOM_TFLOPS,
+                "frac_of_mfma_only_ceiling": achieved / MFMA_ONLY_RANDOM_TFLOPS,
                 "algorithmic_hbm_GBs": by.value / (ev_ms * 1e-3) / 1e9,
                 "hbm_frac": by.value / (ev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
         }
+        if world == 1 and not bwd and args.variant < 0 and not args.no_secondary:
+            line["secondary"] = secondary_measurements(dev)
         if world == 1 and not args.no_cpu_baseline and not bwd:
             try:
                 line["cpu_baseline"] = cpu_baseline(B, H, N, D, causal)

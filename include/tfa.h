@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 104 /* 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
+#define TFA_VERSION 105 /* 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
 
 /* element types */
 enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1, TFA_F32 = 2 /* output only */ };
@@ -66,8 +66,8 @@ enum tfa_status {
   TFA_OK = 0,
   TFA_ERR_NULL = -1,          /* a required pointer is NULL */
   TFA_ERR_DTYPE = -2,         /* dtype not in {F16,BF16}; out_dtype not in {dtype,F32} */
-  TFA_ERR_HEAD_DIM = -3,      /* forward: D not a multiple of 8 in [8,256]; split-KV: not a multiple of 8 in [8,128]; merge: not a multiple
-                               * of 4 in [4,256]; backward: not a multiple of 8 in [8,128] */
+  TFA_ERR_HEAD_DIM = -3,      /* forward, split-KV: D not a multiple of 8 in [8,256]; merge: not a multiple of 4 in [4,256];
+                               * backward, TFA_FWD_EXACT_MAX: not a multiple of 8 in [8,128] */
   TFA_ERR_SHAPE = -4,         /* B,H,Hk,Nq,Nk <= 0 or H % Hk != 0 */
   TFA_ERR_STRIDE = -5,        /* a stride is negative, not 16-byte aligned, rows overlap, or 768 rows of a (b,h) slice span 2 GiB
                                * (tfa_fwd with D <= 128 switches to per-block / per-tile descriptor windows when a slice is larger,
@@ -106,7 +106,18 @@ typedef struct tfa_fwd_params {
    * see no key of the chunk: out = 0, lse = +inf) to be combined with tfa_merge.  Both 0 = the whole sequence. */
   int64_t kv_offset;
   int64_t nk_total;      /* 0 means kv_offset + Nk */
+  int32_t flags;         /* TFA_FWD_* bits, 0 = default */
+  int32_t reserved_;     /* must be 0 */
 } tfa_fwd_params;
+
+/* tfa_fwd_params::flags
+ * TFA_FWD_EXACT_MAX: round P to 16 bits at the REFERENCE's points — every KV tile is exponentiated against the exact running
+ *   row maximum, as flash_attention_cutlass/csrc/flash_attention.cu:263-316 and flash_attention_py/main_torch_only.py:240-260
+ *   do — instead of the default kernels' lazily re-based row reference (same mathematics, O and LSE agree to the P-rounding
+ *   bound, but the 16-bit roundings of P fall elsewhere).  Runs the burst-structured LDS-DMA kernel: head dims up to 128,
+ *   (b,h) slices below 2 GiB, no GQA row packing; 10-15 % slower than the default on large grids.  For callers that compare
+ *   against the reference element by element (rtol 1e-3 with fp32 output). */
+#define TFA_FWD_EXACT_MAX 1
 
 /* Library version (TFA_VERSION of the build). */
 int tfa_version(void);
@@ -161,7 +172,7 @@ int tfa_merge(const float* o_parts, const float* lse_parts, int nparts, int64_t 
 
 /* Split-KV on one GPU in ONE launch (decode-like shapes: few query rows, long K/V, too few workgroups to fill the
  * chip): the key sequence is cut into `splits` chunks (multiples of 64 keys), the grid carries one copy of the work per
- * chunk (LDS-DMA kernel), partials go to `workspace`, tfa_merge writes *p's out (contiguous (B,H,Nq,D)) and lse.
+ * chunk (LDS-DMA kernel; head dims above 128: one launch of the 256-wide kernel per chunk), partials go to `workspace`, tfa_merge writes *p's out (contiguous (B,H,Nq,D)) and lse.
  * workspace: tfa_fwd_splitkv_workspace(p, splits) floats (16-byte aligned); negative return = TFA_ERR_*. */
 long long tfa_fwd_splitkv_workspace(const tfa_fwd_params* p, int splits);
 int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void* stream);

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"include/tfa.h declares {n} but libtfa_hip.so does not export it"
     assert sorted(_lib.SYMBOLS) == names
-    assert L.tfa_version() == 104
+    assert L.tfa_version() == 105
 
 
 def _params(B=2, H=4, Hk=4, Nq=128, Nk=128, D=128, dtype=_lib.TFA_BF16, out_dtype=None, scale=0.1, base=0x10000):
@@ -151,7 +151,50 @@ def test_suggested_split_count():
     assert sug(B=8, H=32, Hk=32, Nq=1, Nk=16384) == 1            # 256 workgroups already
     assert sug(B=1, H=32, Hk=32, Nq=1, Nk=2048) == 1             # short cache: the merge is not worth it
     assert sug(B=4, H=32, Hk=32, Nq=4096, Nk=4096) == 1
-    assert sug(B=1, H=8, Hk=8, Nq=1, Nk=16384, D=256) == 1       # the split-KV kernel stops at D = 128
+    assert sug(B=1, H=8, Hk=8, Nq=1, Nk=16384, D=256) == 1       # D > 128 splits one launch per chunk: never suggested
+
+
+def test_split_suggestion_respects_the_one_descriptor_limit():
+    # a decode call over a long strided KV cache whose (b,h) slice spans more than 2 GiB: tfa_fwd plans it (windowed il kernel),
+    # tfa_fwd_splitkv could not (one descriptor per slice) -> the suggestion must be 1, so that every auto-split caller stays
+    # on tfa_fwd
+    L = _lib.lib()
+    p = _params(B=1, H=8, Hk=1, Nq=1, Nk=300000, D=128)
+    a = p.k_stride; a[0], a[1], a[2] = 300000 * 4096, 128, 4096
+    a = p.v_stride; a[0], a[1], a[2] = 300000 * 4096, 128, 4096
+    assert plan(p)[0] == 0
+    assert L.tfa_fwd_suggest_splits(C.byref(p)) == 1
+    small = _params(B=1, H=8, Hk=1, Nq=1, Nk=300000, D=128)        # the same problem with a dense cache does split
+    assert L.tfa_fwd_suggest_splits(C.byref(small)) > 1
+
+
+def test_gqa_packing_is_an_optimisation_never_a_requirement():
+    # q broadcast over the heads (head stride 0): as rows of a packed problem the "rows do not overlap" check fails, as the
+    # caller described it the call is fine -> run() falls back to the caller's layout instead of returning TFA_ERR_STRIDE
+    p = _params(B=64, H=32, Hk=8, Nq=1, Nk=8192)
+    p.q_stride[1] = 0
+    st, grid, _, _ = plan(p)
+    assert st == 0 and grid == 64 * 32
+    assert _lib.lib().tfa_fwd_variant(C.byref(p)) == _lib.lib().tfa_fwd_variant(C.byref(_params(B=64, H=32, Hk=32, Nq=1, Nk=8192)))
+
+
+def test_exact_max_flag_selects_the_exact_running_max_kernel():
+    L = _lib.lib()
+    p = _params(B=4, H=32, Hk=32, Nq=4096, Nk=4096)
+    assert _lib.variant_name(L.tfa_fwd_variant(C.byref(p))).startswith("il8")
+    p.flags = _lib.TFA_FWD_EXACT_MAX
+    v = L.tfa_fwd_variant(C.byref(p))
+    assert v == 17 and not _lib.lazy_reference(v)
+    assert L.tfa_fwd_suggest_splits(C.byref(p)) == 1
+    g = _params(B=64, H=32, Hk=8, Nq=1, Nk=8192)
+    g.flags = _lib.TFA_FWD_EXACT_MAX
+    assert plan(g)[1] == 64 * 32                                   # no GQA row packing under the flag
+    p.D = 256
+    for name, (h, n) in (("q_stride", (32, 4096)), ("k_stride", (32, 4096)), ("v_stride", (32, 4096)), ("o_stride", (32, 4096))):
+        a = getattr(p, name); a[0], a[1], a[2] = h * n * 256, n * 256, 256
+    assert plan(p)[0] == -3                                         # no exact-max kernel above D = 128
+    p.flags = 2
+    assert plan(p)[0] == -4                                         # unknown flag bits are refused
 
 
 def test_gqa_decode_is_planned_per_kv_head():

@@ -31,24 +31,37 @@ def _worker(rank, world, port, shape, causal, q_out):
     from oracle import oracle as O
     from tiny_flash_attention_amd import dist as tdist
 
-    B, H, N, D = shape
-    q, k, v = O.make_inputs(B, H, N, D, torch.float32, seed=17)   # same seed on every rank
+    B, H, Hk, N, D = shape if len(shape) == 5 else (shape[0], shape[1], shape[1], shape[2], shape[3])
+    q, k, v = O.make_inputs(B, H, N, D, torch.float32, seed=17, Hk=Hk)   # same seed on every rank
     sc = 1.0 / math.sqrt(D)
     fn = lambda a, b, c, cz, s: O.flash_attn(a, b, c, cz, s)
     full = tdist.sharded_forward(q, k, v, causal, sc, fn=fn, gather=True)
     local = tdist.sharded_forward(q, k, v, causal, sc, fn=fn, gather=False)
     ref = O.flash_attn(q, k, v, causal, sc)
-    axis = tdist.shard_axis(B, H, world)
-    ref_local = tdist.local_shard(ref, world, rank, axis)
+    axis = tdist.shard_axis(B, Hk, world)
+    if axis == "batch" or Hk == H:
+        ref_local = tdist.local_shard(ref, world, rank, axis)
+    else:                                                     # GQA on the (batch x K/V head) axis: whole K/V heads with their query heads
+        lo, hi = tdist.shard_bounds(B * Hk, world, rank)
+        G = H // Hk
+        ref_local = ref.reshape(1, B * H, N, D)[:, lo * G:hi * G]
     ok = bool(torch.equal(full, ref)) and bool(torch.equal(local.reshape(ref_local.shape), ref_local))
     # zero-copy: the slab is a view into the full tensor
-    ok = ok and tdist.local_shard(q, world, rank, axis).data_ptr() >= q.data_ptr()
+    ok = ok and tdist.local_shard(q, world, rank, "batch" if axis == "batch" else "bh").data_ptr() >= q.data_ptr()
+    # callers that hold SHARDS (no rank has the full tensors): every rank passes its own batch slab, GQA as it stands
+    if B % world == 0:
+        lo, hi = tdist.shard_bounds(B, world, rank)
+        full2 = tdist.sharded_forward_local(q[lo:hi].contiguous(), k[lo:hi].contiguous(), v[lo:hi].contiguous(), causal, sc, fn=fn, gather=True)
+        mine = tdist.sharded_forward_local(q[lo:hi].contiguous(), k[lo:hi].contiguous(), v[lo:hi].contiguous(), causal, sc, fn=fn, gather=False)
+        ok = ok and bool(torch.equal(full2, ref)) and bool(torch.equal(mine, ref[lo:hi]))
     q_out.put((rank, ok, axis))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shape,causal", [((4, 2, 64, 32), True), ((1, 6, 48, 32), False)])
+@pytest.mark.parametrize("shape,causal", [((4, 2, 64, 32), True), ((1, 6, 48, 32), False),
+                                          ((2, 4, 2, 48, 32), True),      # GQA, batch-sharded (K/V heads stay whole)
+                                          ((1, 8, 2, 48, 32), False)])    # GQA, B < world: whole K/V heads with their query heads
 def test_sharded_forward_gloo_world2(shape, causal):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

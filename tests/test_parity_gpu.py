@@ -148,6 +148,41 @@ def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causa
         _lib.set_variant(-1)
 
 
+@pytest.mark.parametrize("dtype,B,H,Hk,N,Nk,D,causal", [
+    (torch.bfloat16, 2, 4, 4, 1024, 1024, 128, True),
+    (torch.bfloat16, 1, 8, 8, 2048, 2048, 128, False),
+    (torch.bfloat16, 3, 8, 2, 512, 768, 128, True),        # GQA, Nq != Nk
+    (torch.bfloat16, 1, 4, 4, 777, 777, 96, True),         # ragged, padded head dim
+    (torch.float16, 2, 4, 4, 1024, 1024, 64, True),
+])
+def test_exact_running_max_flag(tfa, oracle, dev, dtype, B, H, Hk, N, Nk, D, causal):
+    """TFA_FWD_EXACT_MAX (tfa_fwd_params::flags): P is rounded at the reference's own points — the exact running row maximum
+    of every KV tile (main_torch_only.py:240-260) — so the fp32 output meets BASELINE.json's rtol=1e-3 against
+    oracle.tiled_emulation (the restatement of that loop) element by element, for bf16 as well (T2 in check(): 1e-3*|ref| +
+    1e-4*A), on shapes where the default dispatch would run a lazily re-basing kernel."""
+    from tiny_flash_attention_amd import _lib, ops
+
+    q, k, v = oracle.make_inputs(B, H, N, D, dtype, seed=11, Hk=Hk, Nk=Nk)
+    sc = 1.0 / math.sqrt(D)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    out16, lse = ops.flash_attn_fwd(qd, kd, vd, causal, sc, exact_max=True)
+    out32, _ = ops.flash_attn_fwd(qd, kd, vd, causal, sc, out_f32=True, exact_max=True)
+    torch.cuda.synchronize()
+    assert not _lib.lazy_reference(17)
+    _lib.set_variant(17)          # (check() must not assume GQA row packing: a forced variant says "as given", like the flag)
+    try:
+        check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype, var=17)
+    finally:
+        _lib.set_variant(-1)
+    # and, plainly: rtol 1e-3 against the reference's rounding points wherever the output is not cancelling to ~0
+    emu = oracle.tiled_emulation(q, k, v, causal, sc, 64)
+    A = oracle.abs_weighted(q, k, v, causal, sc)
+    o32 = out32.cpu()
+    big = emu.abs() > 0.05 * A
+    rel = ((o32 - emu).abs() / emu.abs().clamp_min(1e-30))[big]
+    assert (rel > 1e-3).float().mean().item() <= 1e-4, f"rtol 1e-3 exceeded by {(rel > 1e-3).float().mean().item():.2e} of the elements (max rel {rel.max().item():.2e})"
+
+
 @pytest.mark.parametrize("variant", [-1, 17, 30, 31, 33, 35, 36, 37])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
 @pytest.mark.parametrize("Nq,Nk,causal", [(128, 384, True), (384, 128, True), (100, 333, False), (1, 1000, True), (257, 64, False),
                                           (700, 1500, True), (1111, 1111, False)])

@@ -62,7 +62,12 @@ class TfaFwdParams(C.Structure):
         ("out_dtype", C.c_int32),
         ("kv_offset", C.c_int64),
         ("nk_total", C.c_int64),
+        ("flags", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
+
+
+TFA_FWD_EXACT_MAX = 1   # tfa_fwd_params::flags (include/tfa.h)
 
 
 class TfaBwdParams(C.Structure):

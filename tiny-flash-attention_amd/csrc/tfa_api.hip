@@ -34,6 +34,7 @@ bool one_descriptor(const tfa_fwd_params* p) {
 int pick_variant(const tfa_fwd_params* p) {
   if (p && p->D > 128) return tfa::kX4D256Variant;   // one kernel serves 136..256 (a forced variant does not apply)
   if (g_variant >= 0) return g_variant;
+  if (p && (p->flags & TFA_FWD_EXACT_MAX)) return tfa::kSplitVariant;   // the LDS-DMA kernel keeps the exact running max (validate: D <= 128)
   if (!p) return tfa::kDefaultVariant;
   // Measured on MI355X (tests/tools/ab.py, profiles/): 256-row query blocks (8 waves) are fastest when there
   // are enough of them to fill 256 CUs and no causal diagonal; 128-row blocks (two 4-wave workgroups per
@@ -94,6 +95,8 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant, int row_mod = 
   if (p->B <= 0 || p->H <= 0 || p->Hk <= 0 || p->Nq <= 0 || p->Nk <= 0) return TFA_ERR_SHAPE;
   if (p->H % p->Hk != 0) return TFA_ERR_SHAPE;
   if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
+  if ((p->flags & ~TFA_FWD_EXACT_MAX) != 0 || p->reserved_ != 0) return TFA_ERR_SHAPE;
+  if ((p->flags & TFA_FWD_EXACT_MAX) && p->D > 128) return TFA_ERR_HEAD_DIM;          // no exact-max kernel that wide
   const bool ablate = (variant >= 100 && variant < 100 + 512) || (variant >= 700 && variant < 716) || (variant >= 1000 && variant < 2256) || (variant >= 3000 && variant < 3256);   // timing-only ablations (debug)
   if (!ablate && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
   if (p->D != 64 && p->D != 128 && (ablate || !tfa::supports_padded_d(variant))) return TFA_ERR_HEAD_DIM;   // (A/B arms: 64 / 128 only)
@@ -187,7 +190,8 @@ bool pack_gqa_rows(const tfa_fwd_params* p, tfa_fwd_params* o, int* row_mod = nu
 int run(const tfa_fwd_params* p_in, void* stream, tfa::LaunchGeom* geom, bool dry, int* variant_out = nullptr) {
   tfa_fwd_params packed;
   int row_mod = 0;
-  const tfa_fwd_params* p = (g_variant < 0 && !(g_dbg_flags & 4096) && pack_gqa_rows(p_in, &packed, &row_mod, true)) ? &packed : p_in;
+  const bool may_pack = g_variant < 0 && !(g_dbg_flags & 4096) && p_in && !(p_in->flags & TFA_FWD_EXACT_MAX);
+  const tfa_fwd_params* p = (may_pack && pack_gqa_rows(p_in, &packed, &row_mod, true)) ? &packed : p_in;
   int variant = pick_variant(p);
   tfa::KArgs a;
   int st = validate(p, &a, variant, row_mod);
@@ -242,7 +246,7 @@ const char* tfa_strerror(int status) {
     case TFA_OK: return "success";
     case TFA_ERR_NULL: return "tfa: a required pointer is NULL";
     case TFA_ERR_DTYPE: return "tfa: unsupported dtype (q/k/v must be fp16 or bf16; out must match or be fp32)";
-    case TFA_ERR_HEAD_DIM: return "tfa: unsupported head dim (forward: multiples of 8 up to 256; split-KV and backward: multiples of 8 up to 128; merge: multiples of 4 up to 256)";
+    case TFA_ERR_HEAD_DIM: return "tfa: unsupported head dim (forward and split-KV: multiples of 8 up to 256; backward and TFA_FWD_EXACT_MAX: multiples of 8 up to 128; merge: multiples of 4 up to 256)";
     case TFA_ERR_SHAPE: return "tfa: bad shape (sizes must be positive and H % Hk == 0)";
     case TFA_ERR_STRIDE: return "tfa: bad stride (must be >=0, rows 16-byte aligned and non-overlapping; 768 rows of a (b,h) slice must span < 2 GiB, the whole slice for split-KV / backward)";
     case TFA_ERR_ALIGN: return "tfa: base pointers must be 16-byte aligned";
@@ -303,7 +307,8 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   int ns = 0, ch = 0;
   int st = splitkv_geometry(p, splits, &ns, &ch);
   if (st != TFA_OK) return st;
-  if (p->D < 8 || p->D > 128 || (p->D % 8) != 0) return TFA_ERR_HEAD_DIM;   // the LDS-DMA kernel: 64 and 128 wide, any valid width inside
+  if (p->D < 8 || p->D > 256 || (p->D % 8) != 0) return TFA_ERR_HEAD_DIM;
+  if (p->flags & TFA_FWD_EXACT_MAX) return TFA_ERR_SHAPE;                    // (the merge moves the rounding points: see tfa.h)
   if (!workspace || ((uintptr_t)workspace & 15)) return workspace ? TFA_ERR_ALIGN : TFA_ERR_NULL;
   // the merge writes contiguous rows: out must be a contiguous (B,H,Nq,D) tensor
   if (p->o_stride[2] != p->D || p->o_stride[1] != (int64_t)p->Nq * p->D || p->o_stride[0] != (int64_t)p->H * p->Nq * p->D) return TFA_ERR_STRIDE;
@@ -318,6 +323,26 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   {
     tfa_fwd_params qp;                                    // GQA decode: one stream of K/V per K/V head (the workspace rows keep their order)
     if (!(g_dbg_flags & 4096) && pack_gqa_rows(&q, &qp)) q = qp;
+  }
+  if (p->D > 128) {
+    // Head dims 136..256: the one kernel that wide (x4-d256) has no chunk dimension in its grid, so the partial passes are `ns`
+    // launches of tfa_fwd over key chunks (kv_offset / nk_total: the causal mask stays against global key positions) — one
+    // launch per chunk instead of one in all, same partials, same merge.
+    const int64_t rs_k = p->k_stride[2], rs_v = p->v_stride[2];
+    for (int c = 0; c < ns; ++c) {
+      tfa_fwd_params qc = q;
+      const int64_t k0 = (int64_t)c * ch;
+      qc.k = reinterpret_cast<const char*>(p->k) + k0 * rs_k * 2;
+      qc.v = reinterpret_cast<const char*>(p->v) + k0 * rs_v * 2;
+      qc.Nk = (int)((p->Nk - k0) < ch ? (p->Nk - k0) : ch);
+      qc.kv_offset = k0;
+      qc.nk_total = p->Nk;
+      qc.out = ws_o + (long long)c * rows * p->D;
+      qc.lse = ws_l + (long long)c * rows;
+      st = run(&qc, stream, nullptr, false);
+      if (st != TFA_OK) return st;
+    }
+    return tfa_merge(ws_o, ws_l, ns, rows, p->D, rows * p->D, rows, p->out, p->out_dtype, p->lse, stream);
   }
   const int variant = tfa::kSplitVariant;                 // the LDS-DMA kernel carries the chunk dimension in its grid
   tfa::KArgs a;
@@ -341,8 +366,11 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
 
 int tfa_fwd_suggest_splits(const tfa_fwd_params* p_in) {
   if (!p_in || g_variant >= 0) return 1;                  // a forced kernel variant means: run exactly that
+  if (p_in->flags & TFA_FWD_EXACT_MAX) return 1;          // (the merge of partial passes moves the rounding points as well)
   tfa_fwd_params packed;
   const tfa_fwd_params* p = pack_gqa_rows(p_in, &packed) ? &packed : p_in;
+  // (head dims above 128: tfa_fwd_splitkv works — one launch per chunk — but launches on one stream run one after the other, so it
+  //  fills the chip no better than tfa_fwd: never suggested)
   if (p->D > 128 || p->kv_offset != 0 || p->nk_total != 0 || p->B <= 0 || p->H <= 0 || p->Nq <= 0) return 1;
   // tfa_fwd_splitkv runs the one-descriptor-per-slice LDS-DMA kernel: a K/V cache whose (b,h) slice spans 2 GiB or more (long
   // strided caches) stays on tfa_fwd, whose il kernels address it through windows

@@ -37,29 +37,71 @@ def local_shard(t, world, rank, axis):
     return flat[:, lo:hi]
 
 
+def local_shard_gqa(q, k, v, world, rank):
+    """This rank's slab of a GQA problem on the flattened (batch x K/V head) axis: whole K/V heads with all of their query heads.
+    q (B,H,N,D), k/v (B,Hk,Nk,D), contiguous -> views (1, n*G, N, D), (1, n, Nk, D), (1, n, Nk, D)."""
+    B, H, Hk = q.shape[0], q.shape[1], k.shape[1]
+    G = H // Hk
+    lo, hi = shard_bounds(B * Hk, world, rank)
+    qf = q.reshape(1, B * H, *q.shape[2:])[:, lo * G:hi * G]
+    kf = k.reshape(1, B * Hk, *k.shape[2:])[:, lo:hi]
+    vf = v.reshape(1, B * Hk, *v.shape[2:])[:, lo:hi]
+    return qf, kf, vf
+
+
+def _gather_slabs(out_l, world, group):
+    """all-gather of equal contiguous slabs into ONE contiguous buffer (world, *slab): all_gather_into_tensor, not the
+    list form (which stages through per-rank tensors)."""
+    full = torch.empty((world,) + tuple(out_l.shape), dtype=out_l.dtype, device=out_l.device)
+    dist.all_gather_into_tensor(full.view(-1), out_l.contiguous().view(-1), group=group)
+    return full
+
+
+def sharded_forward_local(q_l, k_l, v_l, is_causal, softmax_scale, group=None, gather=True, fn=None):
+    """The multi-GPU entry for callers whose tensors are ALREADY sharded: every rank passes ITS batch slab
+    q_l (B_l,H,N,D), k_l / v_l (B_l,Hk,Nk,D) — no rank ever holds the full tensors — runs the kernel on it (GQA as it stands:
+    a batch slab keeps every K/V head whole) and, with gather=True, returns the (world*B_l, H, N, D) output of all ranks
+    (equal slabs; one all_gather_into_tensor), else its own slab.  The partitioning is the reference's own independence
+    of (b,h) problems (flash_attention_cutlass/csrc/flash_attention.cu:382,409,698): no data-path collective."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if fn is None:
+        fn = lambda a, b_, c, causal, sc: ops.flash_attn_fwd(a, b_, c, causal, sc, return_lse=False)[0]
+    out_l = fn(q_l, k_l, v_l, is_causal, softmax_scale)
+    if not gather or world == 1:
+        return out_l
+    full = _gather_slabs(out_l, world, group)
+    return full.reshape((world * out_l.shape[0],) + tuple(out_l.shape[1:]))
+
+
 def sharded_forward(q, k, v, is_causal, softmax_scale, group=None, gather=True, fn=None):
-    """q,k,v: the FULL (B,H,N,D) tensors, identical on every rank (e.g. broadcast or regenerated from
-    a seed).  Each rank computes its slab; with gather=True every rank returns the full output
-    (all-gather of the slabs, equal slab sizes required), else its local slab.
+    """q,k,v: the FULL (B,H,N,D) / (B,Hk,Nk,D) tensors, identical on every rank (e.g. regenerated from a seed — the
+    synthetic bench; real callers hold shards and use sharded_forward_local).  Each rank computes its slab: whole batches
+    when B divides over the ranks, else flattened (batch x head) units — with GQA whole K/V heads together with their query
+    heads.  gather=True: every rank returns the full output (equal slabs required), else its local slab.
     `fn(q,k,v,is_causal,scale) -> out` defaults to the HIP operator; tests inject a CPU function."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if fn is None:
         fn = lambda a, b_, c, causal, sc: ops.flash_attn_fwd(a, b_, c, causal, sc, return_lse=False)[0]
-    B, H = q.shape[0], q.shape[1]
-    if k.shape[1] != H:
-        raise ValueError("sharded_forward shards whole heads: expand K/V heads (GQA) per rank or shard by batch")
-    axis = shard_axis(B, H, world)
-    ql, kl, vl = (local_shard(t, world, rank, axis) for t in (q, k, v))
+    B, H, Hk = q.shape[0], q.shape[1], k.shape[1]
+    if H % Hk != 0:
+        raise ValueError(f"H={H} is not a multiple of Hk={Hk}")
+    axis = shard_axis(B, Hk if Hk != H else H, world)
+    if axis == "batch":
+        ql, kl, vl = (local_shard(t, world, rank, axis) for t in (q, k, v))
+        units = B
+    elif Hk == H:
+        ql, kl, vl = (local_shard(t, world, rank, axis) for t in (q, k, v))
+        units = B * H
+    else:
+        ql, kl, vl = local_shard_gqa(q, k, v, world, rank)
+        units = B * Hk
     out_l = fn(ql.contiguous(), kl.contiguous(), vl.contiguous(), is_causal, softmax_scale)
     if not gather or world == 1:
         return out_l if world > 1 else out_l.reshape(q.shape)
-    units = B if axis == "batch" else B * H
     if units % world != 0:
         raise ValueError("gather needs equal slabs: units % world_size != 0")
-    full = torch.empty(q.shape, dtype=out_l.dtype, device=out_l.device)
-    dist.all_gather_into_tensor(full.view(-1), out_l.contiguous().view(-1), group=group)
-    return full
+    return _gather_slabs(out_l, world, group).reshape(q.shape)
 
 
 def kv_sharded_forward(q, k_local, v_local, is_causal, softmax_scale, kv_offset, nk_total, group=None,
@@ -96,8 +138,10 @@ class OverlappedGather:
     The slab is cut into `chunks` contiguous batch chunks.  `step()` launches chunk c's kernel on the current stream and
     queues chunk c's all-gather on a side stream behind an event, so that RCCL moves chunk c over xGMI while chunk c+1
     computes; only the last chunk's gather is exposed.  (b,h) problems are independent
-    (flash_attention_cutlass/csrc/flash_attention.cu:382,409,698), so chunking changes no result bit.  `full` holds the
-    gathered output, rank r's batch b at row r*B + b; `join()` makes the current stream wait for the outstanding gathers.
+    (flash_attention_cutlass/csrc/flash_attention.cu:382,409,698), so chunking changes no result bit.  Each chunk is gathered
+    with ONE all_gather_into_tensor into its own contiguous buffer `parts[c]` (world, rows, H, N, D); `result()` (alias
+    `full`) joins and returns the whole (world*B, H, N, D) output, rank r's batch b at row r*B + b; `join()` makes the
+    current stream wait for the outstanding gathers.
     `fn(q,k,v,is_causal,scale,out) -> None` defaults to the HIP operator writing into `out`; `device='cpu'` tensors
     (the gloo tests) run the same schedule without streams."""
 
@@ -109,29 +153,45 @@ class OverlappedGather:
         self.nchunks = max(1, min(int(chunks), B))
         self.bounds = [shard_bounds(B, self.nchunks, c) for c in range(self.nchunks)]
         self.out = torch.empty_like(q)
-        self.full = torch.empty((world * B,) + tuple(q.shape[1:]), dtype=q.dtype, device=q.device)
+        # one CONTIGUOUS (world, chunk rows, H, N, D) buffer per chunk: a chunk's gather is a single all_gather_into_tensor
+        self.parts = [torch.empty((world, hi - lo) + tuple(q.shape[1:]), dtype=q.dtype, device=q.device) for lo, hi in self.bounds]
         self.cuda = q.is_cuda
         if fn is None:
             fn = lambda a, b_, c, causal, sc, o: ops.flash_attn_fwd(a, b_, c, causal, sc, return_lse=False, out=o)
         self.fn = fn
         if self.cuda:
             self.side = torch.cuda.Stream(device=q.device)
+            # allocated on the caller's stream, used on the side stream (and RCCL's): tell the caching allocator, so that
+            # dropping this object while gathers are in flight cannot hand the memory out early
+            self.out.record_stream(self.side)
+            for t in self.parts:
+                t.record_stream(self.side)
             self.computed = [torch.cuda.Event() for _ in self.bounds]
             self.gathered = [None for _ in self.bounds]      # event of the chunk's last gather (its out slab is being read)
 
-    def _gather(self, lo, hi):
-        B = self.q.shape[0]
+    def _gather(self, c, lo, hi):
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
-            self.full[lo:hi].copy_(self.out[lo:hi])
+            self.parts[c][0].copy_(self.out[lo:hi])
             return
-        dsts = [self.full[r * B + lo: r * B + hi] for r in range(self.world)]
-        dist.all_gather(dsts, self.out[lo:hi], group=self.group)
+        dist.all_gather_into_tensor(self.parts[c].view(-1), self.out[lo:hi].reshape(-1), group=self.group)
+
+    def result(self):
+        """The gathered output of all ranks, (world*B, H, N, D) with rank r's batch b at row r*B + b, after join().
+        (Assembled from the per-chunk buffers: a copy when there is more than one chunk — consumers that can work chunk by
+        chunk read `parts[c]`, shape (world, rows of chunk c, H, N, D), directly.)"""
+        self.join()
+        full = self.parts[0] if self.nchunks == 1 else torch.cat(self.parts, dim=1)
+        return full.reshape((self.world * self.q.shape[0],) + tuple(self.q.shape[1:]))
+
+    @property
+    def full(self):
+        return self.result()
 
     def step(self):
         if not self.cuda:
-            for lo, hi in self.bounds:
+            for c, (lo, hi) in enumerate(self.bounds):
                 self.fn(self.q[lo:hi], self.k[lo:hi], self.v[lo:hi], self.causal, self.scale, self.out[lo:hi])
-                self._gather(lo, hi)
+                self._gather(c, lo, hi)
             return
         main = torch.cuda.current_stream(self.q.device)
         for c, (lo, hi) in enumerate(self.bounds):
@@ -141,7 +201,7 @@ class OverlappedGather:
             self.computed[c].record(main)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.computed[c])
-                self._gather(lo, hi)
+                self._gather(c, lo, hi)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
                 self.gathered[c] = ev

@@ -32,13 +32,15 @@ def _strides_bhnd(t, layout):
 
 
 def flash_attn_fwd(q, k, v, is_causal=False, softmax_scale=None, *, layout="bhnd", out_f32=False,
-                   return_lse=True, out=None, kv_offset=0, nk_total=None, auto_split=False):
+                   return_lse=True, out=None, kv_offset=0, nk_total=None, auto_split=False, exact_max=False):
     """General forward: q (B,H,Nq,D) / k,v (B,Hk,Nk,D) for ``layout='bhnd'`` or
     (B,N,H,D) for ``layout='bnhd'``; any batch/head/row strides, unit stride along D.
     Returns ``(out, lse)``; ``out`` has q's shape (fp32 when ``out_f32``), ``lse`` is (B,H,Nq) fp32.
     Maps onto tfa_fwd (include/tfa.h); semantics per flash_attention_c/csrc/attn.cpp:101-169 and
     flash_attention_cutlass/csrc/flash_attention.cu:536-630.  ``auto_split``: decode-like shapes (few query rows, long K/V)
-    go through tfa_fwd_splitkv with the chunk count tfa_fwd_suggest_splits names (what the reference-named entry points do)."""
+    go through tfa_fwd_splitkv with the chunk count tfa_fwd_suggest_splits names (what the reference-named entry points do).
+    ``exact_max``: TFA_FWD_EXACT_MAX — P is rounded to 16 bits at the reference's own points (exact running row maximum per
+    KV tile, main_torch_only.py:240-260); head dims up to 128."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         if not t.is_cuda:
             raise RuntimeError(f"{n} must be a CUDA tensor")
@@ -88,6 +90,7 @@ def flash_attn_fwd(q, k, v, is_causal=False, softmax_scale=None, *, layout="bhnd
     p.out_dtype = _lib.TFA_F32 if out.dtype == torch.float32 else _DT[out.dtype]
     p.kv_offset = int(kv_offset)                     # split-KV: k, v are keys [kv_offset, kv_offset+Nk) of nk_total
     p.nk_total = 0 if nk_total is None else int(nk_total)
+    p.flags = _lib.TFA_FWD_EXACT_MAX if exact_max else 0
     L = _lib.lib()
     # tfa_fwd_splitkv's merge writes a dense (B,H,Nq,D) result: gate on the exact strides it checks (is_contiguous() ignores the
     # strides of size-1 dims, and Nq == 1 is the very shape auto-split targets)
