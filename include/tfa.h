@@ -218,8 +218,12 @@ typedef struct tfa_bwd_params {
   int grad_dtype;        /* == dtype, or TFA_F32 */
 } tfa_bwd_params;
 
-/* Launch delta + dQ + dK + dV kernels on `stream` (asynchronous). */
+/* Launch the backward on `stream` (asynchronous): delta, dQ (S, dP, dQ: 3 GEMM units), then dK and dV in ONE launch that computes S and
+ * dP once each (4 units; tfa_bwd_kv_kernel.h).  Deterministic: no atomics, fixed summation order. */
 int tfa_bwd(const tfa_bwd_params* p, void* stream);
+/* Debug / A-B (per thread): on != 0 makes tfa_bwd run dK and dV as two single-gradient launches (S computed twice: the form of
+ * versions <= 0.1.4). */
+int tfa_debug_bwd_split(int on);
 /* Validate *p without launching (no GPU needed). */
 int tfa_bwd_plan(const tfa_bwd_params* p);
 /* Algorithmic work of one call: flops = 2.5 x the forward's (5 GEMMs of 2*Nq*Nk*D each per head, halved

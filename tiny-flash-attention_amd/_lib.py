@@ -32,6 +32,7 @@ SYMBOLS = (
     "tfa_fwd_suggest_splits",
     "tfa_bwd",
     "tfa_bwd_plan",
+    "tfa_debug_bwd_split",
     "tfa_bwd_work",
     "tfa_bwd_time",
 )
@@ -193,6 +194,11 @@ def set_variant(v):
 def debug_set_flags(flags):
     """Bring-up flags of the calling thread (include/tfa.h: tfa_debug_set_flags); 0 = normal."""
     check(lib().tfa_debug_set_flags(int(flags)))
+
+
+def debug_bwd_split(on):
+    """tfa_debug_bwd_split: dK and dV as two launches (A/B and cross-check of the fused dK/dV kernel)."""
+    check(lib().tfa_debug_bwd_split(1 if on else 0))
 
 
 def get_variant():

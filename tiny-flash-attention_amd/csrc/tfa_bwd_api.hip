@@ -13,6 +13,10 @@ template <> hipError_t launch_bwd<__bf16, 64>(const BArgs&, int, int, bool, bool
 template <> hipError_t launch_bwd<__bf16, 128>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_bwd<_Float16, 64>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_bwd<_Float16, 128>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd_kv<__bf16, 64>(const BArgs&, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd_kv<__bf16, 128>(const BArgs&, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd_kv<_Float16, 64>(const BArgs&, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd_kv<_Float16, 128>(const BArgs&, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_delta<__bf16, 64>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
 template <> hipError_t launch_delta<__bf16, 128>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
 template <> hipError_t launch_delta<_Float16, 64>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
@@ -20,6 +24,8 @@ template <> hipError_t launch_delta<_Float16, 128>(const void*, const void*, flo
 }  // namespace tfa
 
 namespace {
+
+thread_local int g_bwd_split = 0;   // tfa_debug_bwd_split(1): dK and dV as two launches (the round-1/2 form), for A/B and parity cross-checks
 
 bool slice_bytes(int64_t n, int64_t row_stride, int d, int esize, unsigned* out) {
   const int64_t bytes = ((n - 1) * row_stride + d) * esize;
@@ -111,9 +117,25 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   }
   int st = launch(tfa::BWD_DQ, p->dq, p->dq_stride, p->Nq, p->H);
   if (st) return st;
-  st = launch(tfa::BWD_DK, p->dk, p->dk_stride, p->Nk, p->Hk);
-  if (st) return st;
-  return launch(tfa::BWD_DV, p->dv, p->dv_stride, p->Nk, p->Hk);
+  if (g_bwd_split) {                                       // debug / A-B: the two single-gradient launches (S computed twice)
+    st = launch(tfa::BWD_DK, p->dk, p->dk_stride, p->Nk, p->Hk);
+    if (st) return st;
+    return launch(tfa::BWD_DV, p->dv, p->dv_stride, p->Nk, p->Hk);
+  }
+  // dK and dV in one launch: S and dP once each (tfa_bwd_kv_kernel.h)
+  tfa::BArgs m = a;
+  m.grad = p->dk; m.gs_b = p->dk_stride[0]; m.gs_h = p->dk_stride[1]; m.gs_n = p->dk_stride[2];
+  m.grad2 = p->dv; m.g2s_b = p->dv_stride[0]; m.g2s_h = p->dv_stride[1]; m.g2s_n = p->dv_stride[2];
+  if (!slice_bytes(p->Nk, p->dk_stride[2], p->D, gsz, &m.g_bytes) || !slice_bytes(p->Nk, p->dv_stride[2], p->D, gsz, &m.g2_bytes)) return TFA_ERR_STRIDE;
+  m.nrb = (p->Nk + 127) / 128;
+  const int64_t grid = (int64_t)p->B * p->Hk * m.nrb;
+  if (grid >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
+  hipError_t e;
+  if (p->dtype == TFA_BF16)
+    e = wide ? tfa::launch_bwd_kv<__bf16, 128>(m, (int)grid, causal, f32, s, dry) : tfa::launch_bwd_kv<__bf16, 64>(m, (int)grid, causal, f32, s, dry);
+  else
+    e = wide ? tfa::launch_bwd_kv<_Float16, 128>(m, (int)grid, causal, f32, s, dry) : tfa::launch_bwd_kv<_Float16, 64>(m, (int)grid, causal, f32, s, dry);
+  return (int)e;
 }
 
 }  // namespace
@@ -122,6 +144,7 @@ extern "C" {
 
 int tfa_bwd(const tfa_bwd_params* p, void* stream) { return run_bwd(p, stream, false); }
 int tfa_bwd_plan(const tfa_bwd_params* p) { return run_bwd(p, nullptr, true); }
+int tfa_debug_bwd_split(int on) { g_bwd_split = on ? 1 : 0; return TFA_OK; }
 
 int tfa_bwd_work(const tfa_bwd_params* p, double* flops, double* bytes) {
   const int st = run_bwd(p, nullptr, true);

@@ -40,8 +40,11 @@ struct BArgs {
   int B, H, Hk, Nq, Nk;
   int dv;                    // valid head dim (multiple of 8, <= the kernel's width D): 16-byte chunks beyond it are read as zeros
                              // (their offsets point out of the descriptor's range, TFA_OOB) and never stored
-  int nrb;                   // 256-row resident blocks per (b, resident head)
+  int nrb;                   // resident blocks per (b, resident head): 256 rows (bwd_kernel) or 128 keys (bwd_kv_kernel)
   float scale, scale_log2;
+  void* grad2;               // bwd_kv_kernel (tfa_bwd_kv_kernel.h): `grad` = dK, `grad2` = dV
+  long long g2s_b, g2s_h, g2s_n;
+  unsigned g2_bytes;
 };
 
 enum { BWD_DQ = 0, BWD_DK = 1, BWD_DV = 2 };

@@ -1,0 +1,266 @@
+// tfa_bwd_kv_kernel.h — dK and dV in ONE launch: S and dP are computed once each (4 GEMM units where the two
+// single-gradient launches of tfa_bwd_kernel.h execute 5: S twice).  gfx950.
+//
+// A wave that owned both accumulator sets would need 128 accumulator + 64 resident-fragment registers before any working
+// state — more than the 256 a wave has with two waves per SIMD.  So the work of one block of resident keys is split by ROLE
+// between the two waves that share a SIMD (waves w and w+4 of the workgroup, same 32 keys):
+//     role 0 (waves 0-3):  S^T = Qtile . K^T   ->  P = exp2(S*scale - LSE)  ->  dV^T += dOtile^T . P        resident: K rows
+//     role 1 (waves 4-7):  dP^T = dOtile . V^T ->  dS = P o (dP - delta)    ->  dK^T += Qtile^T . dS        resident: V rows
+// P goes from role 0 to role 1 through LDS as the 16-bit values the dV product consumes, in the lane-private register layout
+// (same lane = same key in both waves: a straight copy, no transposition).  Role 1 runs ONE TILE BEHIND role 0, so the copy is
+// ordered by the tile loop's one barrier and neither wave waits for the other inside a tile:
+//     iteration it:   role 0 works on tile it (writes P(it) into exchange buffer it&1),
+//                     role 1 works on tile it-1 (reads P(it-1) from buffer (it-1)&1);  LDS-DMA fills tile it+1.
+// Three tile stages of two images each (Q and dO, row-major with the u_swz XOR swizzle of tfa_bwd_kernel.h: one image
+// serves the b128 row reads of GEMM-I and the transpose reads of GEMM-II), 128 resident keys per workgroup (4 key groups x 2
+// roles = 8 waves), every layout the forward's (verified on hardware).  Deterministic: no atomics, fixed summation order.
+// GQA: the streamed sequence runs over the G query heads of the K/V head, as in tfa_bwd_kernel.h.
+#pragma once
+#include "tfa_bwd_kernel.h"
+
+namespace tfa {
+
+template <typename T, int D, bool CAUSAL, bool F32OUT>
+__global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
+  using E = Elem<T>;
+  using X8 = typename E::x8;
+  constexpr int NW = 8, KG = 4;
+  constexpr int BMK = KG * 32;                     // resident keys per workgroup
+  constexpr int BN = 64;                           // streamed query rows per tile
+  constexpr int CPR = D / 8;
+  constexpr int TILE_BYTES = BN * D * 2;
+  constexpr int PIECES = TILE_BYTES / 1024;
+  constexpr int PPW = PIECES / NW;
+  constexpr int DS = D / 16;
+  constexpr int DT = D / 32;
+  constexpr int NSTAGE = 3;
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // image 0: Q tile, image 1: dO tile
+  constexpr int PX_BYTES = 32 * BN * 2;            // one key group's P tile, 16 bit
+  static_assert(PPW >= 1 && PPW * NW == PIECES, "");
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  char* const pbuf = smem + NSTAGE * STAGE_BYTES;  // [2 parities][KG][PX_BYTES]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave & 3;                         // key group: rows r0 + 32*kg ..
+  const int role = wave >> 2;                      // 0: S, P, dV     1: dP, dS, dK
+  const int qi = lane & 31;
+  const int hi = lane >> 5;
+
+  const int G = p.H / p.Hk;
+  int rb, bhr;
+  {
+    const int nbh = p.B * p.Hk, id = blockIdx.x;   // a (b, K/V head) stays on one XCD; causal: the block with the most tiles first
+    if ((nbh & 7) == 0) {
+      const int x = id & 7, q8 = id >> 3;
+      bhr = x + 8 * (q8 / p.nrb);
+      rb = q8 % p.nrb;
+    } else {
+      bhr = id / p.nrb;
+      rb = id % p.nrb;
+    }
+  }
+  const int b = bhr / p.Hk;
+  const int hr = bhr - b * p.Hk;
+  const int shift = p.Nk - p.Nq;
+  const int r0 = rb * BMK;
+  const int wave_row0 = r0 + kg * 32;
+  const int my_row = wave_row0 + qi;
+
+  // ---- streamed tile range of this block (query tiles that see key r0 or later ones) -----------------------------
+  int t_begin = 0;
+  const int t_end = (p.Nq + BN - 1) / BN;
+  if (CAUSAL) {
+    const int qmin = r0 - shift;                   // first query row that sees key r0
+    t_begin = qmin > 0 ? qmin / BN : 0;
+    if (t_begin > t_end) t_begin = t_end;
+  }
+  const int ntl = t_end - t_begin;                 // tiles per streamed head
+  const int nu = ntl * G;                          // tiles of the flat (head-major) sequence
+
+  // ---- per-lane DMA source offsets of the two images ---------------------------------------------------------------
+  int src[2][PPW];
+  int tile_stride[2];
+#pragma unroll
+  for (int img = 0; img < 2; ++img) {
+    const int sn = (int)(img ? p.dout.s_n : p.q.s_n);
+    tile_stride[img] = BN * sn * 2;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;
+      const int row = pc * (1024 / (D * 2)) + lane / CPR;
+      const int cpos = lane % CPR;
+      const int ch = cpos ^ u_swz<D>(row);
+      src[img][i] = ch * 8 < p.dv ? row * sn * 2 + (ch << 4) : (int)TFA_OOB;
+    }
+  }
+  auto dma_issue = [&](int u, int stage) {
+    const int g = u / ntl;
+    const int jt = t_begin + (u - g * ntl);
+    const int hs = hr * G + g;
+#pragma unroll
+    for (int img = 0; img < 2; ++img) {
+      const BTensor& x = img ? p.dout : p.q;
+      const T* base = reinterpret_cast<const T*>(x.p) + b * x.s_b + hs * x.s_h;
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < PPW; ++i)
+        lds_dma16_m0(rs, lds_base + stage * STAGE_BYTES + img * TILE_BYTES + (wave * PPW + i) * 1024, src[img][i] + jt * tile_stride[img]);
+    }
+  };
+
+  // ---- resident fragments: role 0 holds its K rows, role 1 its V rows ------------------------------------------------
+  X8 rf[DS];
+  {
+    const BTensor& x = role ? p.v : p.k;
+    const T* b1 = reinterpret_cast<const T*>(x.p) + b * x.s_b + hr * x.s_h;
+    auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, x.bytes, 0x00020000);
+    const int off1 = my_row * (int)x.s_n * 2 + hi * 16;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) rf[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs1, (2 * s + hi) * 8 < p.dv ? off1 + s * 32 : (int)TFA_OOB, 0, 0));
+  }
+
+  f32x16 acc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+  const int k_rd_base = qi * (D * 2);
+  const int k_rd_swz = u_swz<D>(qi);
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  // transpose reads of the row-major image: this lane addresses 4 consecutive d (8 bytes) of tile row 16*sl + tr_row (first read)
+  // and 16*sl + tr_row + 8 (second read); chunk = 4*dtile + tr_clo, XOR-swizzled by the row (tfa_bwd_kernel.h, UNI)
+  const int tr_row = 4 * hi + (i16 >> 2);
+  const int tr_clo = 2 * g16 + ((i16 & 3) >> 1);
+  const int tr_byte = ((i16 & 3) & 1) * 8;
+  const int tr_s1 = u_swz<D>(tr_row), tr_s2 = u_swz<D>(tr_row + 8);
+  const int tr_b1 = tr_row * (D * 2) + tr_byte, tr_b2 = (tr_row + 8) * (D * 2) + tr_byte;
+  const float sc = p.scale_log2;
+
+  if (nu > 0) dma_issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(rf[s]));
+  asm volatile("s_barrier" ::: "memory");
+
+  int st_next = 1;                                   // stage of tile it+1
+  int st_mine = role ? NSTAGE - 1 : 0;               // stage of this wave's tile (role 1: tile it-1)
+#pragma nounroll
+  for (int it = 0; it <= nu; ++it) {
+    if (it + 1 < nu) dma_issue(it + 1, st_next);     // that stage held tile it-2: role 1 left it at the last barrier
+    const int u = it - role;
+    if (u >= 0 && u < nu) {
+      const int g = u / ntl;
+      const int jt = t_begin + (u - g * ntl);
+      const int row0 = jt * BN;                      // first query row of the tile
+      const char* img_q = smem + st_mine * STAGE_BYTES;
+      const char* img_do = img_q + TILE_BYTES;
+      const char* img1 = role ? img_do : img_q;      // GEMM-I operand rows (role 0: Q, role 1: dO)
+      const char* imgt = role ? img_q : img_do;      // GEMM-II transposed operand (role 0: dO, role 1: Q)
+      char* const px = pbuf + ((u & 1) * KG + kg) * PX_BYTES;
+
+      // this wave's 32 keys x 64 queries: anything masked?  everything masked?
+      const bool need_mask = CAUSAL && (row0 < wave_row0 + 31 - shift);
+      const bool active = !CAUSAL || (row0 + BN - 1 >= wave_row0 - shift);
+      // per tile-row statistics: LSE (role 0) or delta (role 1) of the (b, query head) row; out of range -> 0
+      const long long so = (long long)(b * p.H + hr * G + g) * p.Nq;
+      auto st_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((role ? p.delta : p.lse) + so), 0, (unsigned)p.Nq * 4u, 0x00020000);
+
+      if (active) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          // ---- GEMM-I over the 32 tile rows of half t: S (role 0) or dP (role 1) -----------------------------------
+          f32x16 x;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] = 0.f;
+#pragma unroll
+          for (int sl = 0; sl < DS; ++sl) {
+            const int off = k_rd_base + t * 32 * (D * 2) + (((2 * sl + hi) ^ k_rd_swz) << 4);
+            x = E::mfma(__builtin_bit_cast(X8, lds_read_b128(img1, off)), rf[sl], x);
+          }
+          float stv[16];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int q = row0 + 32 * t + 8 * g4 + 4 * hi;
+            const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(st_rs, q * 4, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stv[4 * g4 + e] = a[e];
+          }
+          X8 pk[2];
+          if (role == 0) {
+            if (need_mask) {
+              const int limq = my_row - shift - row0 - 4 * hi;     // query offsets below this do not see the lane's key
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int qo = 32 * t + (r & 3) + 8 * (r >> 2);
+                if (qo < limq) x[r] = -INFINITY;
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pk[r >> 3][r & 7] = (T)fast_exp2(fmaf(x[r], sc, -stv[r] * 1.4426950408889634f));
+            // hand P to the role-1 wave of this key group (it reads it in the next iteration)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lds_write_b128(px, (t * 2 + j) * 1024 + lane * 16, __builtin_bit_cast(u32x4, pk[j]));
+          } else {
+            X8 pp[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pp[j] = __builtin_bit_cast(X8, lds_read_b128(px, (t * 2 + j) * 1024 + lane * 16));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pk[r >> 3][r & 7] = (T)((float)pp[r >> 3][r & 7] * (x[r] - stv[r]));
+          }
+          // ---- GEMM-II for the two 16-row slots of this half: dV^T += dO^T . P  /  dK^T += Q^T . dS ----------------
+#pragma unroll
+          for (int sl = 2 * t; sl < 2 * t + 2; ++sl)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+              const int c = 4 * d + tr_clo;
+              const s16x4 lo = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b1 + ((c ^ tr_s1) << 4));
+              const s16x4 hh = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b2 + ((c ^ tr_s2) << 4));
+              const s16x8 vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+              acc[d] = E::mfma(__builtin_bit_cast(X8, vf), pk[sl - 2 * t], acc[d]);
+            }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    st_next = st_next + 1 == NSTAGE ? 0 : st_next + 1;
+    st_mine = st_mine + 1 == NSTAGE ? 0 : st_mine + 1;
+  }
+
+  // ---- epilogue: role 0 writes dV, role 1 writes dK * scale.  acc[dt][r] = grad[row my_row][32*dt + (r&3) + 8*(r>>2) + 4*hi] ----
+  const float osc = role ? p.scale : 1.f;
+  void* const gp = role ? p.grad : p.grad2;
+  const long long gsb = role ? p.gs_b : p.g2s_b, gsh = role ? p.gs_h : p.g2s_h;
+  const int gsn = (int)(role ? p.gs_n : p.g2s_n);
+  const unsigned gbytes = role ? p.g_bytes : p.g2_bytes;
+  if (F32OUT) {
+    float* gb = reinterpret_cast<float*>(gp) + b * gsb + hr * gsh;
+    auto g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, gbytes, 0x00020000);
+    const int goff = my_row * gsn * 4 + hi * 16;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 v4 = {acc[d][4 * g4 + 0] * osc, acc[d][4 * g4 + 1] * osc, acc[d][4 * g4 + 2] * osc, acc[d][4 * g4 + 3] * osc};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), g_rs, d * 32 + g4 * 8 + hi * 4 < p.dv ? goff + (d * 32 + g4 * 8) * 4 : (int)TFA_OOB, 0, 0);
+      }
+  } else {
+    T* gb = reinterpret_cast<T*>(gp) + b * gsb + hr * gsh;
+    auto g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, gbytes, 0x00020000);
+    const int goff = my_row * gsn * 2 + hi * 8;
+    typedef __attribute__((ext_vector_type(4))) T t4;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        t4 v4 = {(T)(acc[d][4 * g4 + 0] * osc), (T)(acc[d][4 * g4 + 1] * osc), (T)(acc[d][4 * g4 + 2] * osc), (T)(acc[d][4 * g4 + 3] * osc)};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), g_rs, d * 32 + g4 * 8 + hi * 4 < p.dv ? goff + (d * 32 + g4 * 8) * 2 : (int)TFA_OOB, 0, 0);
+      }
+  }
+}
+
+}  // namespace tfa

@@ -2,11 +2,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "tfa_bwd_kernel.h"
+#include "tfa_bwd_kv_kernel.h"
 #include "tfa_host_util.h"
 
 namespace tfa {
 template <typename T, int D>
 hipError_t launch_bwd(const BArgs& a, int mode, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);
+// dK and dV in one launch (tfa_bwd_kv_kernel.h): grid = B * Hk * ceil(Nk / 128)
+template <typename T, int D>
+hipError_t launch_bwd_kv(const BArgs& a, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);
 template <typename T, int D>
 hipError_t launch_delta(const void* o, const void* dout, float* delta, const long long* os, const long long* ds, int H, int Nq, long long rows,
                         int dv, hipStream_t stream, bool dry);

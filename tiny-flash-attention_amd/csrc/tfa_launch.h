@@ -9,7 +9,8 @@
 #include "tfa_fwd_kernel_dma.h"
 #include "tfa_fwd_kernel_il.h"
 #include "tfa_fwd_kernel_x4.h"
-#if defined(TFA_EXPERIMENTAL)
+#if defined(TFA_EXPERIMENTAL)   // measured dead ends, kept out of the package: experiments/csrc (the Makefile adds the include path)
+#include "tfa_fwd_kernel_bringup.h"
 #include "tfa_fwd_kernel_pp.h"
 #include "tfa_fwd_kernel_swp.h"
 #include "tfa_fwd_kernel_w64.h"

@@ -1,5 +1,5 @@
 """Backward timing on the BASELINE shapes: tfa_bwd_time (delta + dQ + dK + dV kernels per call).
-TFLOP/s uses the conventional 2.5 x forward flops (5 GEMMs); the kernels execute 8 GEMM units (S three times, dP twice).
+TFLOP/s uses the conventional 2.5 x forward flops (5 GEMMs); the kernels execute 7 GEMM units (dQ launch: S, dP, dQ; fused dK/dV launch: S, dP, dV, dK).
 usage: python tools/bench_bwd.py [--cfgs cfg3,cfg3nc,cfg4] [--iters 20]"""
 import argparse, ctypes as C, math, os, sys
 import torch
@@ -26,13 +26,19 @@ for cfg in a.cfgs.split(","):
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fl, by = C.c_double(), C.c_double()
     _lib.check(_lib.lib().tfa_bwd_work(C.byref(p), C.byref(fl), C.byref(by)))
-    best = 1e9
+    best, best_split = 1e9, 1e9
     for r in range(3):
         ms = C.c_float()
         _lib.check(_lib.lib().tfa_bwd_time(C.byref(p), 3, a.iters, s, C.byref(ms)))
         best = min(best, ms.value)
+        _lib.debug_bwd_split(True)                     # the 8-GEMM form: dK and dV as two launches
+        try:
+            _lib.check(_lib.lib().tfa_bwd_time(C.byref(p), 3, a.iters, s, C.byref(ms)))
+        finally:
+            _lib.debug_bwd_split(False)
+        best_split = min(best_split, ms.value)
     pf = ops.make_params(q, k, v, out, lse, causal, sc)
     msf = C.c_float()
     _lib.check(_lib.lib().tfa_fwd_time(C.byref(pf), 3, a.iters, s, C.byref(msf)))
-    print(f"{cfg:7s} bwd {best:7.3f} ms = {fl.value / best / 1e9:7.1f} TFLOP/s (2.5x-fwd convention; {fl.value / best / 1e9 * 1.6:7.1f} executed) "
-          f"| fwd {msf.value:6.3f} ms | bwd/fwd = {best / msf.value:.2f} | algorithmic {by.value / 1e6:.0f} MB")
+    print(f"{cfg:7s} bwd {best:7.3f} ms = {fl.value / best / 1e9:7.1f} TFLOP/s (2.5x-fwd convention; {fl.value / best / 1e9 * 1.4:7.1f} executed) "
+          f"| fwd {msf.value:6.3f} ms | bwd/fwd = {best / msf.value:.2f} | algorithmic {by.value / 1e6:.0f} MB | two-launch dK,dV form: {best_split:7.3f} ms")
