@@ -216,16 +216,26 @@ typedef struct tfa_bwd_params {
   int is_causal;
   int dtype;             /* TFA_F16 / TFA_BF16: q,k,v,out,dout */
   int grad_dtype;        /* == dtype, or TFA_F32 */
+  /* Optional: a scratch buffer of at least tfa_bwd_workspace_bytes(p) bytes (16-byte aligned), or NULL.  With it the dK/dV launch
+   * keeps dS = P o (dP - delta) (16 bit, B*H*Nk*Nq elements) and dQ becomes ONE GEMM over it instead of a recomputation of S and
+   * dP: 5 GEMM units in all instead of 7, at the price of O(Nq*Nk) scratch memory.  Same results (the same 16-bit dS feeds dQ
+   * either way, up to P having been rounded to 16 bit first), still deterministic.  NULL / too small: the O(N)-memory path. */
+  void* workspace;
+  int64_t workspace_bytes;
 } tfa_bwd_params;
 
 /* Launch the backward on `stream` (asynchronous): delta, dQ (S, dP, dQ: 3 GEMM units), then dK and dV in ONE launch that computes S and
- * dP once each (4 units; tfa_bwd_kv_kernel.h).  Deterministic: no atomics, fixed summation order. */
+ * dP once each (4 units; tfa_bwd_kv_kernel.h); with tfa_bwd_params::workspace: delta, dK/dV (which also writes dS), dQ = dS.K (1 unit).
+ * Deterministic: no atomics, fixed summation order. */
 int tfa_bwd(const tfa_bwd_params* p, void* stream);
 /* Debug / A-B (per thread): on != 0 makes tfa_bwd run dK and dV as two single-gradient launches (S computed twice: the form of
  * versions <= 0.1.4). */
 int tfa_debug_bwd_split(int on);
 /* Validate *p without launching (no GPU needed). */
 int tfa_bwd_plan(const tfa_bwd_params* p);
+/* Bytes of tfa_bwd_params::workspace that switch tfa_bwd to its 5-GEMM form for *p (B*H * roundup(Nk,128) * roundup(Nq,256) * 2),
+ * 0 when that form does not apply (a head's slab would reach 2 GiB), negative = TFA_ERR_*. */
+long long tfa_bwd_workspace_bytes(const tfa_bwd_params* p);
 /* Algorithmic work of one call: flops = 2.5 x the forward's (5 GEMMs of 2*Nq*Nk*D each per head, halved
  * when causal), bytes = q,k,v,out,dout read once + dq,dk,dv written once + lse. */
 int tfa_bwd_work(const tfa_bwd_params* p, double* flops, double* bytes);

@@ -55,8 +55,12 @@ def check_grads(oracle, grads32, grads16, q, k, v, out16, dout, causal, sc, dtyp
         assert (g16c - r).abs().max().item() <= 1e-2 * max(1.0, r.abs().max().item()), f"(B3) {name}"
 
 
-def run_bwd_case(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, seed=0, scale=None, layout="bhnd"):
-    from tiny_flash_attention_amd import ops
+MODES = ["default", "workspace", "split"]   # tfa_bwd's forms: 7 GEMM units (fused dK/dV launch), 5 (dS kept in a caller-lent
+                                            # workspace, dQ = dS.K), 8 (dK and dV as two launches: the debug A/B arm)
+
+
+def run_bwd_case(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, seed=0, scale=None, layout="bhnd", mode="default"):
+    from tiny_flash_attention_amd import _lib, ops
 
     q, k, v = oracle.make_inputs(B, H, Nq, D, dtype, seed=seed, Hk=Hk, Nk=Nk)
     dout = make_dout(B, H, Nq, D, dtype, seed + 100)
@@ -65,9 +69,14 @@ def run_bwd_case(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, seed=0, s
     if layout == "bnhd":
         qd, kd, vd, dod = (t.transpose(1, 2).contiguous() for t in (qd, kd, vd, dod))
     out, lse = ops.flash_attn_fwd(qd, kd, vd, causal, sc, layout=layout)
-    g32 = ops.flash_attn_bwd(qd, kd, vd, out, lse, dod, causal, sc, layout=layout, grad_f32=True)
-    g16 = ops.flash_attn_bwd(qd, kd, vd, out, lse, dod, causal, sc, layout=layout)
-    torch.cuda.synchronize()
+    ws = True if mode == "workspace" else None
+    _lib.debug_bwd_split(mode == "split")
+    try:
+        g32 = ops.flash_attn_bwd(qd, kd, vd, out, lse, dod, causal, sc, layout=layout, grad_f32=True, workspace=ws)
+        g16 = ops.flash_attn_bwd(qd, kd, vd, out, lse, dod, causal, sc, layout=layout, workspace=ws)
+        torch.cuda.synchronize()
+    finally:
+        _lib.debug_bwd_split(False)
     if layout == "bnhd":
         g32 = tuple(t.transpose(1, 2) for t in g32)
         g16 = tuple(t.transpose(1, 2) for t in g16)
@@ -95,16 +104,43 @@ BWD_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D,causal", BWD_SHAPES)
-def test_bwd_parity(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal):
-    run_bwd_case(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, seed=3)
+def test_bwd_parity(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, mode):
+    run_bwd_case(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, seed=3, mode=mode)
 
 
-def test_bwd_strided_bnhd_matches_bhnd(tfa, oracle, dev):
-    a = run_bwd_case(tfa, oracle, dev, torch.bfloat16, 2, 8, 2, 384, 384, 128, True, seed=5, scale=0.09)
-    b = run_bwd_case(tfa, oracle, dev, torch.bfloat16, 2, 8, 2, 384, 384, 128, True, seed=5, scale=0.09, layout="bnhd")
+@pytest.mark.parametrize("mode", ["default", "workspace"])
+def test_bwd_strided_bnhd_matches_bhnd(tfa, oracle, dev, mode):
+    a = run_bwd_case(tfa, oracle, dev, torch.bfloat16, 2, 8, 2, 384, 384, 128, True, seed=5, scale=0.09, mode=mode)
+    b = run_bwd_case(tfa, oracle, dev, torch.bfloat16, 2, 8, 2, 384, 384, 128, True, seed=5, scale=0.09, layout="bnhd", mode=mode)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_bwd_workspace_form_agrees_with_the_default(tfa, oracle, dev):
+    """dK and dV come from the same launch in both forms (bit-identical); dQ from the kept dS differs from the recomputing
+    launch only by P having been rounded to 16 bit before dS was formed: inside the (B1) bound, and deterministic."""
+    from tiny_flash_attention_amd import ops
+
+    q, k, v = (t.to(dev) for t in oracle.make_inputs(2, 8, 1280, 128, torch.bfloat16, seed=21, Hk=4, Nk=1536))
+    dout = make_dout(2, 8, 1280, 128, torch.bfloat16, 22).to(dev)
+    out, lse = ops.flash_attn_fwd(q, k, v, True, 0.09)
+    g0 = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, 0.09)
+    big = torch.full((64 << 20,), 0xFF, dtype=torch.uint8, device=dev)          # a caller-owned scratch buffer full of NaN patterns
+    g1 = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, 0.09, workspace=big)
+    g2 = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, 0.09, workspace=big)
+    torch.cuda.synchronize()
+    assert torch.equal(g0[1], g1[1]) and torch.equal(g0[2], g1[2])
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    d = (g0[0].float() - g1[0].float()).abs().max().item()
+    assert bool(torch.isfinite(g1[0].float()).all()) and d <= 2e-2 * g0[0].float().abs().max().item(), d
+    small = torch.empty((1024,), dtype=torch.uint8, device=dev)                  # too small: silently the O(N)-memory form
+    g3 = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, 0.09, workspace=small)
+    torch.cuda.synchronize()
+    for a, b in zip(g0, g3):
+        assert torch.equal(a, b)
 
 
 def test_bwd_deterministic_and_inputs_untouched(tfa, oracle, dev):

@@ -33,6 +33,7 @@ SYMBOLS = (
     "tfa_bwd",
     "tfa_bwd_plan",
     "tfa_debug_bwd_split",
+    "tfa_bwd_workspace_bytes",
     "tfa_bwd_work",
     "tfa_bwd_time",
 )
@@ -103,6 +104,8 @@ class TfaBwdParams(C.Structure):
         ("is_causal", C.c_int32),
         ("dtype", C.c_int32),
         ("grad_dtype", C.c_int32),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64),
     ]
 
 

@@ -17,6 +17,10 @@ template <> hipError_t launch_bwd_kv<__bf16, 64>(const BArgs&, int, bool, bool, 
 template <> hipError_t launch_bwd_kv<__bf16, 128>(const BArgs&, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_bwd_kv<_Float16, 64>(const BArgs&, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_bwd_kv<_Float16, 128>(const BArgs&, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd_dq_ws<__bf16, 64>(const BArgs&, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd_dq_ws<__bf16, 128>(const BArgs&, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd_dq_ws<_Float16, 64>(const BArgs&, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd_dq_ws<_Float16, 128>(const BArgs&, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_delta<__bf16, 64>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
 template <> hipError_t launch_delta<__bf16, 128>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
 template <> hipError_t launch_delta<_Float16, 64>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
@@ -48,6 +52,15 @@ int check_strides(const int64_t* st, int d, int esize) {
   }
   if (st[2] < d) return TFA_ERR_STRIDE;
   return TFA_OK;
+}
+
+// bytes of the dS workspace for *p, 0 when a head's slab (roundup(Nk,128) x roundup(Nq,256) x 2 bytes) would not fit one descriptor
+long long ws_bytes(const tfa_bwd_params* p, int* nk_pad, int* nq_pad) {
+  const long long nk = ((long long)p->Nk + 127) / 128 * 128, nq = ((long long)p->Nq + 255) / 256 * 256;
+  if (nk_pad) *nk_pad = (int)nk;
+  if (nq_pad) *nq_pad = (int)nq;
+  if (nk * nq * 2 >= (long long)0x7fffffff) return 0;
+  return (long long)p->B * p->H * nk * nq * 2;
 }
 
 int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
@@ -115,6 +128,39 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
                : tfa::launch_delta<_Float16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry);
     if (e != hipSuccess) return (int)e;
   }
+  // ---- with a workspace: dK/dV launch that also writes dS, then dQ = scale * dS . K (5 GEMM units) -----------------------------
+  int nk_pad = 0, nq_pad = 0;
+  const long long need = ws_bytes(p, &nk_pad, &nq_pad);
+  if (p->workspace && (((uintptr_t)p->workspace) & 15)) return TFA_ERR_ALIGN;
+  const bool use_ws = p->workspace != nullptr && need > 0 && p->workspace_bytes >= need && !g_bwd_split;
+  if (use_ws) {
+    tfa::BArgs m = a;
+    m.ws = p->workspace; m.ws_nk = nk_pad; m.ws_nq = nq_pad;
+    m.grad = p->dk; m.gs_b = p->dk_stride[0]; m.gs_h = p->dk_stride[1]; m.gs_n = p->dk_stride[2];
+    m.grad2 = p->dv; m.g2s_b = p->dv_stride[0]; m.g2s_h = p->dv_stride[1]; m.g2s_n = p->dv_stride[2];
+    if (!slice_bytes(p->Nk, p->dk_stride[2], p->D, gsz, &m.g_bytes) || !slice_bytes(p->Nk, p->dv_stride[2], p->D, gsz, &m.g2_bytes)) return TFA_ERR_STRIDE;
+    m.nrb = (p->Nk + 127) / 128;
+    int64_t grid = (int64_t)p->B * p->Hk * m.nrb;
+    if (grid >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
+    hipError_t e;
+    if (p->dtype == TFA_BF16)
+      e = wide ? tfa::launch_bwd_kv<__bf16, 128>(m, (int)grid, causal, f32, s, dry) : tfa::launch_bwd_kv<__bf16, 64>(m, (int)grid, causal, f32, s, dry);
+    else
+      e = wide ? tfa::launch_bwd_kv<_Float16, 128>(m, (int)grid, causal, f32, s, dry) : tfa::launch_bwd_kv<_Float16, 64>(m, (int)grid, causal, f32, s, dry);
+    if (e != hipSuccess) return (int)e;
+    tfa::BArgs d = a;
+    d.ws = p->workspace; d.ws_nk = nk_pad; d.ws_nq = nq_pad;
+    d.grad = p->dq; d.gs_b = p->dq_stride[0]; d.gs_h = p->dq_stride[1]; d.gs_n = p->dq_stride[2];
+    if (!slice_bytes(p->Nq, p->dq_stride[2], p->D, gsz, &d.g_bytes)) return TFA_ERR_STRIDE;
+    d.nrb = (p->Nq + 255) / 256;
+    grid = (int64_t)p->B * p->H * d.nrb;
+    if (grid >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
+    if (p->dtype == TFA_BF16)
+      e = wide ? tfa::launch_bwd_dq_ws<__bf16, 128>(d, (int)grid, causal, f32, s, dry) : tfa::launch_bwd_dq_ws<__bf16, 64>(d, (int)grid, causal, f32, s, dry);
+    else
+      e = wide ? tfa::launch_bwd_dq_ws<_Float16, 128>(d, (int)grid, causal, f32, s, dry) : tfa::launch_bwd_dq_ws<_Float16, 64>(d, (int)grid, causal, f32, s, dry);
+    return (int)e;
+  }
   int st = launch(tfa::BWD_DQ, p->dq, p->dq_stride, p->Nq, p->H);
   if (st) return st;
   if (g_bwd_split) {                                       // debug / A-B: the two single-gradient launches (S computed twice)
@@ -145,6 +191,15 @@ extern "C" {
 int tfa_bwd(const tfa_bwd_params* p, void* stream) { return run_bwd(p, stream, false); }
 int tfa_bwd_plan(const tfa_bwd_params* p) { return run_bwd(p, nullptr, true); }
 int tfa_debug_bwd_split(int on) { g_bwd_split = on ? 1 : 0; return TFA_OK; }
+long long tfa_bwd_workspace_bytes(const tfa_bwd_params* p) {
+  tfa_bwd_params q;
+  if (!p) return TFA_ERR_NULL;
+  q = *p;
+  q.workspace = nullptr;
+  const int st = run_bwd(&q, nullptr, true);
+  if (st) return st;
+  return ws_bytes(p, nullptr, nullptr);
+}
 
 int tfa_bwd_work(const tfa_bwd_params* p, double* flops, double* bytes) {
   const int st = run_bwd(p, nullptr, true);

@@ -45,6 +45,8 @@ struct BArgs {
   void* grad2;               // bwd_kv_kernel (tfa_bwd_kv_kernel.h): `grad` = dK, `grad2` = dV
   long long g2s_b, g2s_h, g2s_n;
   unsigned g2_bytes;
+  void* ws;                  // optional dS workspace (tfa_bwd_params::workspace): dS^T[b][query head][ws_nk key rows][ws_nq queries], 16 bit
+  int ws_nk, ws_nq;          // padded extents: Nk rounded up to 128, Nq rounded up to 256
 };
 
 enum { BWD_DQ = 0, BWD_DK = 1, BWD_DV = 2 };

@@ -20,7 +20,12 @@
 
 namespace tfa {
 
-template <typename T, int D, bool CAUSAL, bool F32OUT>
+// WS: role 1 also writes dS (16 bit, without the softmax scale) to BArgs::ws as dS^T[b, query head][key block][query tile][128
+// keys][64 queries] (Nk, Nq rounded up to 128 / 256) — for bwd_dq_ws_kernel (tfa_bwd_dq_kernel.h), which turns it into dQ with ONE
+// GEMM instead of recomputing S and dP.  Every (128-key block, 64-query tile) pair this kernel visits is written completely
+// (fully masked 32-key pieces as zeros); pairs it does not visit are entirely above the causal diagonal and the consumer
+// never reads them.
+template <typename T, int D, bool CAUSAL, bool F32OUT, bool WS = false>
 __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
   using E = Elem<T>;
   using X8 = typename E::x8;
@@ -141,6 +146,30 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
   const int tr_b1 = tr_row * (D * 2) + tr_byte, tr_b2 = (tr_row + 8) * (D * 2) + tr_byte;
   const float sc = p.scale_log2;
 
+  // WS: this lane's 16 dS values of a 32-query half (queries qh + 8*g4 + 4*hi + 0..3, g4 = 0..3) -> dS^T[key my_row][...]
+  auto ws_store = [&](int g, int qh, const X8 (&y)[2]) {
+    // BLOCKED layout: the 128 keys x 64 queries of one (key block, query tile) pair are 16 KiB contiguous (key rows of 128 bytes),
+    // pairs ordered [key block][query tile] — a wave's stores of a tile stay inside one 4 KiB span instead of striding over 32
+    // rows 2*Nq bytes apart (a power-of-two stride: measured 1.2 TB/s), and the consumer's [64 keys][64 queries] sub-blocks are
+    // contiguous.  The two lanes of a key hold interleaved runs of 4 queries (4*hi + 8*g4 ..): one v_permlane32_swap per dword
+    // regroups them into 16 consecutive queries per lane (lower half-wave: queries 0-15 of the half, upper: 16-31), so a lane
+    // stores 2 x 16 bytes instead of 4 x 8.
+    T* const slab = reinterpret_cast<T*>(p.ws) + (long long)(b * p.H + hr * G + g) * p.ws_nk * p.ws_nq;
+    auto w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, (unsigned)((long long)p.ws_nk * p.ws_nq * 2), 0x00020000);
+    const int jt = qh >> 6;
+    const int off = (((rb * (p.ws_nq >> 6) + jt) * BMK + kg * 32 + qi) * BN + (qh & 63) + 16 * hi) * 2;
+    u32x4 A = __builtin_bit_cast(u32x4, y[0]), B = __builtin_bit_cast(u32x4, y[1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned a_ = A[i], b_ = B[i];
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a_), "+v"(b_));
+      A[i] = a_; B[i] = b_;
+    }
+    const u32x4 w0 = {A[0], A[1], B[0], B[1]}, w1 = {A[2], A[3], B[2], B[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(w0, w_rs, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(w1, w_rs, off + 16, 0, 0);
+  };
+
   if (nu > 0) dma_issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -170,7 +199,30 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
       const long long so = (long long)(b * p.H + hr * G + g) * p.Nq;
       auto st_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((role ? p.delta : p.lse) + so), 0, (unsigned)p.Nq * 4u, 0x00020000);
 
+      bool stored = false;
+      if (WS && role == 1 && !active) {              // a fully masked piece of a visited (block, tile) pair: zeros
+        X8 z[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) z[j][e] = (T)0.f;
+        ws_store(g, row0, z);
+        ws_store(g, row0 + 32, z);
+        stored = true;
+      }
       if (active) {
+        // statistics of the 64 tile rows first (both halves): no load is issued between the dS stores below and the barrier
+        float stv[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int q = row0 + 32 * t + 8 * g4 + 4 * hi;
+            const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(st_rs, q * 4, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stv[t][4 * g4 + e] = a[e];
+          }
+        X8 keep[2][2];                                  // WS: dS of both halves, stored behind the tile's last MFMA
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           // ---- GEMM-I over the 32 tile rows of half t: S (role 0) or dP (role 1) -----------------------------------
@@ -181,14 +233,6 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
           for (int sl = 0; sl < DS; ++sl) {
             const int off = k_rd_base + t * 32 * (D * 2) + (((2 * sl + hi) ^ k_rd_swz) << 4);
             x = E::mfma(__builtin_bit_cast(X8, lds_read_b128(img1, off)), rf[sl], x);
-          }
-          float stv[16];
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int q = row0 + 32 * t + 8 * g4 + 4 * hi;
-            const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(st_rs, q * 4, 0, 0));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) stv[4 * g4 + e] = a[e];
           }
           X8 pk[2];
           if (role == 0) {
@@ -201,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
               }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pk[r >> 3][r & 7] = (T)fast_exp2(fmaf(x[r], sc, -stv[r] * 1.4426950408889634f));
+            for (int r = 0; r < 16; ++r) pk[r >> 3][r & 7] = (T)fast_exp2(fmaf(x[r], sc, -stv[t][r] * 1.4426950408889634f));
             // hand P to the role-1 wave of this key group (it reads it in the next iteration)
 #pragma unroll
             for (int j = 0; j < 2; ++j) lds_write_b128(px, (t * 2 + j) * 1024 + lane * 16, __builtin_bit_cast(u32x4, pk[j]));
@@ -210,7 +254,8 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) pp[j] = __builtin_bit_cast(X8, lds_read_b128(px, (t * 2 + j) * 1024 + lane * 16));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pk[r >> 3][r & 7] = (T)((float)pp[r >> 3][r & 7] * (x[r] - stv[r]));
+            for (int r = 0; r < 16; ++r) pk[r >> 3][r & 7] = (T)((float)pp[r >> 3][r & 7] * (x[r] - stv[t][r]));
+            if (WS) { keep[t][0] = pk[0]; keep[t][1] = pk[1]; }
           }
           // ---- GEMM-II for the two 16-row slots of this half: dV^T += dO^T . P  /  dK^T += Q^T . dS ----------------
 #pragma unroll
@@ -224,6 +269,19 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
               acc[d] = E::mfma(__builtin_bit_cast(X8, vf), pk[sl - 2 * t], acc[d]);
             }
         }
+        if (WS && role == 1) {
+          ws_store(g, row0, keep[0]);
+          ws_store(g, row0 + 32, keep[1]);
+          stored = true;
+        }
+      }
+      // WS: the 4 dS stores of this tile are the wave's YOUNGEST vector-memory operations (vmcnt counts stores and retires in
+      // issue order): leave them in flight across the barrier — everything older, the LDS-DMA pieces of tile it+1 included, is done
+      if (WS && stored) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        st_next = st_next + 1 == NSTAGE ? 0 : st_next + 1;
+        st_mine = st_mine + 1 == NSTAGE ? 0 : st_mine + 1;
+        continue;
       }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "tfa_bwd_kernel.h"
 #include "tfa_bwd_kv_kernel.h"
+#include "tfa_bwd_dq_kernel.h"
 #include "tfa_host_util.h"
 
 namespace tfa {
@@ -10,7 +11,10 @@ template <typename T, int D>
 hipError_t launch_bwd(const BArgs& a, int mode, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);
 // dK and dV in one launch (tfa_bwd_kv_kernel.h): grid = B * Hk * ceil(Nk / 128)
 template <typename T, int D>
-hipError_t launch_bwd_kv(const BArgs& a, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);
+hipError_t launch_bwd_kv(const BArgs& a, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);   // a.ws != nullptr: also writes dS
+// dQ = scale * dS . K from the workspace (tfa_bwd_dq_kernel.h): grid = B * H * ceil(Nq / 256)
+template <typename T, int D>
+hipError_t launch_bwd_dq_ws(const BArgs& a, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);
 template <typename T, int D>
 hipError_t launch_delta(const void* o, const void* dout, float* delta, const long long* os, const long long* ds, int H, int Nq, long long rows,
                         int dv, hipStream_t stream, bool dry);

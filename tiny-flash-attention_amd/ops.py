@@ -212,11 +212,13 @@ def make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, is_causal, softm
     return p
 
 
-def flash_attn_bwd(q, k, v, out, lse, dout, is_causal=False, softmax_scale=None, *, layout="bhnd", grad_f32=False):
+def flash_attn_bwd(q, k, v, out, lse, dout, is_causal=False, softmax_scale=None, *, layout="bhnd", grad_f32=False, workspace=None):
     """Backward of ``flash_attn_fwd``: returns ``(dq, dk, dv)`` shaped like q, k, v (fp32 when ``grad_f32``).
     ``out`` and ``lse`` are the forward's results for the same q, k, v; ``dout`` is the upstream gradient
     (shape/dtype of ``out``).  The reference has no backward — it only saves the LSE for one
-    (flash_attention_cutlass/csrc/flash_attention.cu:353-354,614-623); maps onto tfa_bwd (include/tfa.h)."""
+    (flash_attention_cutlass/csrc/flash_attention.cu:353-354,614-623); maps onto tfa_bwd (include/tfa.h).
+    ``workspace``: None (default: the O(N)-memory 7-GEMM form), True (allocate tfa_bwd_workspace_bytes of scratch for this call)
+    or a caller-owned uint8 / any-dtype CUDA tensor of at least that many bytes: tfa_bwd then keeps dS and executes 5 GEMMs."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
         if not t.is_cuda:
             raise RuntimeError(f"{n} must be a CUDA tensor")
@@ -242,10 +244,28 @@ def flash_attn_bwd(q, k, v, out, lse, dout, is_causal=False, softmax_scale=None,
     dv = torch.empty(v.shape, dtype=gdt, device=q.device)
     delta = torch.empty(lse.shape, dtype=torch.float32, device=q.device)
     p = make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, is_causal, softmax_scale, layout)
+    if workspace is not None and workspace is not False:
+        need = bwd_workspace_bytes(p)
+        if workspace is True:
+            workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=q.device)
+        if not isinstance(workspace, torch.Tensor) or not workspace.is_cuda or workspace.device != q.device or not workspace.is_contiguous():
+            raise RuntimeError("workspace must be True or a contiguous CUDA tensor on q's device")
+        p.workspace = workspace.data_ptr()
+        p.workspace_bytes = workspace.numel() * workspace.element_size()
     with torch.cuda.device(q.device):
         stream = torch.cuda.current_stream().cuda_stream
         _lib.check(_lib.lib().tfa_bwd(C.byref(p), C.c_void_p(stream)))
     return dq, dk, dv
+
+
+def bwd_workspace_bytes(p):
+    """tfa_bwd_workspace_bytes for a TfaBwdParams (0: the 5-GEMM form does not apply to this problem)."""
+    L = _lib.lib()
+    L.tfa_bwd_workspace_bytes.restype = C.c_longlong
+    n = L.tfa_bwd_workspace_bytes(C.byref(p))
+    if n < 0:
+        _lib.check(int(n))
+    return int(n)
 
 
 # ---------------------------------------------------------------------------------------------

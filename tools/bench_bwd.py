@@ -26,7 +26,9 @@ for cfg in a.cfgs.split(","):
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fl, by = C.c_double(), C.c_double()
     _lib.check(_lib.lib().tfa_bwd_work(C.byref(p), C.byref(fl), C.byref(by)))
-    best, best_split = 1e9, 1e9
+    best, best_split, best_ws = 1e9, 1e9, 1e9
+    need = ops.bwd_workspace_bytes(p)
+    ws = torch.empty((need,), dtype=torch.uint8, device=dev) if need > 0 else None
     for r in range(3):
         ms = C.c_float()
         _lib.check(_lib.lib().tfa_bwd_time(C.byref(p), 3, a.iters, s, C.byref(ms)))
@@ -37,8 +39,15 @@ for cfg in a.cfgs.split(","):
         finally:
             _lib.debug_bwd_split(False)
         best_split = min(best_split, ms.value)
+        if ws is not None:                             # the 5-GEMM form: dS kept in a workspace, dQ = dS.K
+            p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
+            try:
+                _lib.check(_lib.lib().tfa_bwd_time(C.byref(p), 3, a.iters, s, C.byref(ms)))
+            finally:
+                p.workspace, p.workspace_bytes = None, 0
+            best_ws = min(best_ws, ms.value)
     pf = ops.make_params(q, k, v, out, lse, causal, sc)
     msf = C.c_float()
     _lib.check(_lib.lib().tfa_fwd_time(C.byref(pf), 3, a.iters, s, C.byref(msf)))
     print(f"{cfg:7s} bwd {best:7.3f} ms = {fl.value / best / 1e9:7.1f} TFLOP/s (2.5x-fwd convention; {fl.value / best / 1e9 * 1.4:7.1f} executed) "
-          f"| fwd {msf.value:6.3f} ms | bwd/fwd = {best / msf.value:.2f} | algorithmic {by.value / 1e6:.0f} MB | two-launch dK,dV form: {best_split:7.3f} ms")
+          f"| fwd {msf.value:6.3f} ms | bwd/fwd = {best / msf.value:.2f} | algorithmic {by.value / 1e6:.0f} MB | two-launch dK,dV form: {best_split:7.3f} ms | with a {need / 1e9:.2f} GB dS workspace (5 GEMMs): {best_ws:7.3f} ms = {fl.value / best_ws / 1e9:7.1f} TFLOP/s")
