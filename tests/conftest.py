@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: tens of seconds of host fp64 oracle work (all 128 headline heads); part of the default -m gpu suite")
 
 
 @pytest.fixture(scope="session")

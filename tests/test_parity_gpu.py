@@ -21,6 +21,7 @@ Tolerances (floating point; stated here once, used by check()):
   (T5) LSE (fp32) vs oracle: |d| <= 1e-4; the +inf pattern of empty rows must match exactly.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -445,6 +446,52 @@ def test_headline_all_heads_vs_device_fp32_and_sampled_heads_vs_oracle(tfa, orac
     for (b, h) in heads[:8 if B == 4 else 2]:
         sl = lambda t: t[b:b + 1, h:h + 1].cpu()
         check(oracle, sl(out), sl(out32), sl(lse), sl(q), sl(k), sl(v), True, sc, torch.bfloat16, var=var)
+
+
+@pytest.mark.slow      # (~15 s of host fp64 work on the GPU box's 128 threads: cheap enough to run with every -m gpu suite)
+def test_headline_every_head_vs_fp64_oracle(tfa, oracle, dev):
+    """BASELINE config 3 at full size, ALL 128 (b,h) heads against the fp64 oracle (the default suite samples 8):
+    16-bit out within the reference's bar (T1, atol 1e-2), fp32 out inside the rigorous P-rounding bound (T3: 2^-8 * A), LSE
+    within 1e-4 (T5).  The oracle is the OpenMP C restatement (oracle/ref_attn.c: oracle_attn_exact64), four heads per call."""
+    from tiny_flash_attention_amd import ops
+
+    B, H, N, D = 4, 32, 4096, 128
+    q, k, v = _headline(dev, seed=77)
+    sc = 1.0 / math.sqrt(D)
+    out, lse = tfa.flash_attention_v2_cutlass(q, k, v, True, sc)
+    out32, _ = ops.flash_attn_fwd(q, k, v, True, sc, out_f32=True)
+    torch.cuda.synchronize()
+    worst16 = worst32 = worst_lse = 0.0
+    for b in range(B):
+        for h0 in range(0, H, 4):
+            sl = lambda t: t[b:b + 1, h0:h0 + 4].cpu()
+            exact, lse_x = oracle.exact64(sl(q), sl(k), sl(v), True, sc, return_lse=True)
+            A = oracle.abs_weighted(sl(q), sl(k), sl(v), True, sc)
+            worst16 = max(worst16, (sl(out).float() - exact).abs().max().item())
+            worst32 = max(worst32, ((sl(out32) - exact).abs() - (2.0 ** -8 * A + 1e-6)).max().item())
+            worst_lse = max(worst_lse, (sl(lse) - lse_x).abs().max().item())
+    print(f"all 128 heads: max|out16 - fp64| = {worst16:.3e}, worst excess over the 2^-8*A bound = {worst32:.3e}, max|dLSE| = {worst_lse:.3e}")
+    assert worst16 <= 1e-2 and worst32 <= 0.0 and worst_lse <= 1e-4
+
+
+def test_headline_shape_fp16_all_heads_vs_device_fp32_and_sampled_heads_vs_oracle(tfa, oracle, dev):
+    """The headline shape in the reference's own tested dtype (fp16, flash_attention_cutlass/test.py:79-87): every head against a
+    device fp32 reference at atol 1e-2 / 1e-3, four whole heads against the fp64 oracle through check() (T1-T5)."""
+    from tiny_flash_attention_amd import _lib, ops
+
+    B, H, N, D = 4, 32, 4096, 128
+    q, k, v = _headline(dev, dtype=torch.float16, seed=41)
+    sc = 1.0 / math.sqrt(D)
+    out, lse = tfa.flash_attention_v2_cutlass(q, k, v, True, sc)
+    out32, _ = ops.flash_attn_fwd(q, k, v, True, sc, out_f32=True)
+    ref = _gpu_fp32_reference(q, k, v, True, sc)
+    torch.cuda.synchronize()
+    assert (out.float() - ref).abs().max().item() <= 1e-2
+    assert (out32 - ref).abs().max().item() <= 1e-3
+    var = _lib.variant_for(B, H, H, N, N, D, True, _lib.TFA_F16)
+    for (b, h) in [(0, 0), (3, 31), (1, 9), (2, 20)]:
+        sl = lambda t: t[b:b + 1, h:h + 1].cpu()
+        check(oracle, sl(out), sl(out32), sl(lse), sl(q), sl(k), sl(v), True, sc, torch.float16, var=var)
 
 
 @pytest.mark.parametrize("causal", [False, True])
