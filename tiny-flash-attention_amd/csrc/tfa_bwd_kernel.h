@@ -169,16 +169,26 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
       }
     }
   }
-  // flat tile u -> (streamed head, tile index); the descriptors are rebuilt per call (a few SALU instructions)
+  // flat tile u -> (streamed head, tile index).  dQ (one streamed head per workgroup): the descriptors are built once; the
+  // key-resident modes rebuild them per call (GQA walks G query heads)
+  __amdgpu_buffer_rsrc_t rs_fixed[NIMG];
+  if (!KEYS_RES) {
+#pragma unroll
+    for (int img = 0; img < NIMG; ++img) {
+      const BTensor& x = img_tensor(img);
+      const T* base = reinterpret_cast<const T*>(x.p) + b * x.s_b + (hr / G) * x.s_h;
+      rs_fixed[img] = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000);
+    }
+  }
   auto dma_issue = [&](int u, int stage) {
-    const int g = u / ntl;
+    const int g = KEYS_RES ? u / ntl : 0;
     const int jt = t_begin + (u - g * ntl);
     const int hs = KEYS_RES ? (hr * G + g) : (hr / G);
 #pragma unroll
     for (int img = 0; img < NIMG; ++img) {
       const BTensor& x = img_tensor(img);
       const T* base = reinterpret_cast<const T*>(x.p) + b * x.s_b + hs * x.s_h;
-      auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000);
+      auto rs = KEYS_RES ? __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000) : rs_fixed[img];
 #pragma unroll
       for (int i = 0; i < PPW; ++i)
         lds_dma16_m0(rs, lds_base + (stage * NIMG + img) * TILE_BYTES + (wave * PPW + i) * 1024, src[img][i] + jt * tile_stride[img]);
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
   for (int u = 0; u < nu; ++u) {
     const int stage = u & 1;
     if (u + 1 < nu) dma_issue(u + 1, stage ^ 1);     // the other stage was released by the barrier that ended tile u-1
-    const int g = u / ntl;
+    const int g = KEYS_RES ? u / ntl : 0;
     const int jt = t_begin + (u - g * ntl);
     const int row0 = jt * BN;                        // first streamed row of the tile (a key for dQ, a query for dK/dV)
     const char* img0 = smem + (stage * NIMG + 0) * TILE_BYTES;

@@ -102,18 +102,25 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
       src[img][i] = ch * 8 < p.dv ? row * sn * 2 + (ch << 4) : (int)TFA_OOB;
     }
   }
-  auto dma_issue = [&](int u, int stage) {
-    const int g = u / ntl;
-    const int jt = t_begin + (u - g * ntl);
-    const int hs = hr * G + g;
+  // The streamed (b, query head) changes every ntl tiles (G > 1 only): descriptors live in SGPRs and are rebuilt at head
+  // boundaries, tile positions are counted — a division, two 64-bit base computations and two descriptors per tile and wave
+  // were 3.8 SALU instructions per MFMA (PMC: profiles/r03_pmc_bwd_kv_cfg3.txt before this change)
+  auto head_rsrc = [&](const BTensor& x, int g) {
+    const T* base = reinterpret_cast<const T*>(x.p) + b * x.s_b + (hr * G + g) * x.s_h;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000);
+  };
+  auto q_rs = head_rsrc(p.q, 0), do_rs = head_rsrc(p.dout, 0);
+  int jt_d = t_begin, g_d = 0;                     // position of the NEXT tile to request
+  auto dma_next = [&](int stage) {
 #pragma unroll
-    for (int img = 0; img < 2; ++img) {
-      const BTensor& x = img ? p.dout : p.q;
-      const T* base = reinterpret_cast<const T*>(x.p) + b * x.s_b + hs * x.s_h;
-      auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000);
+    for (int i = 0; i < PPW; ++i)
+      lds_dma16_m0(q_rs, lds_base + stage * STAGE_BYTES + (wave * PPW + i) * 1024, src[0][i] + jt_d * tile_stride[0]);
 #pragma unroll
-      for (int i = 0; i < PPW; ++i)
-        lds_dma16_m0(rs, lds_base + stage * STAGE_BYTES + img * TILE_BYTES + (wave * PPW + i) * 1024, src[img][i] + jt * tile_stride[img]);
+    for (int i = 0; i < PPW; ++i)
+      lds_dma16_m0(do_rs, lds_base + stage * STAGE_BYTES + TILE_BYTES + (wave * PPW + i) * 1024, src[1][i] + jt_d * tile_stride[1]);
+    if (++jt_d == t_end) {
+      jt_d = t_begin;
+      if (++g_d < G) { q_rs = head_rsrc(p.q, g_d); do_rs = head_rsrc(p.dout, g_d); }
     }
   };
 
@@ -170,21 +177,30 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
     __builtin_amdgcn_raw_buffer_store_b128(w1, w_rs, off + 16, 0, 0);
   };
 
-  if (nu > 0) dma_issue(0, 0);
+  if (nu > 0) dma_next(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(rf[s]));
   asm volatile("s_barrier" ::: "memory");
 
+  int jt_c = t_begin, g_c = 0;                       // this wave's tile: position inside the head, head
+  // per tile-row statistics: LSE (role 0) or delta (role 1) of the (b, query head) row; out of range -> 0
+  auto stat_rsrc = [&](int g) {
+    const long long so = (long long)(b * p.H + hr * G + g) * p.Nq;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((role ? p.delta : p.lse) + so), 0, (unsigned)p.Nq * 4u, 0x00020000);
+  };
+  auto st_rs = stat_rsrc(0);
+  auto next_tile = [&]() {
+    if (++jt_c == t_end) { jt_c = t_begin; if (++g_c < G) st_rs = stat_rsrc(g_c); }
+  };
   int st_next = 1;                                   // stage of tile it+1
   int st_mine = role ? NSTAGE - 1 : 0;               // stage of this wave's tile (role 1: tile it-1)
 #pragma nounroll
   for (int it = 0; it <= nu; ++it) {
-    if (it + 1 < nu) dma_issue(it + 1, st_next);     // that stage held tile it-2: role 1 left it at the last barrier
+    if (it + 1 < nu) dma_next(st_next);              // tile it+1; that stage held tile it-2: role 1 left it at the last barrier
     const int u = it - role;
     if (u >= 0 && u < nu) {
-      const int g = u / ntl;
-      const int jt = t_begin + (u - g * ntl);
+      const int g = g_c, jt = jt_c;
       const int row0 = jt * BN;                      // first query row of the tile
       const char* img_q = smem + st_mine * STAGE_BYTES;
       const char* img_do = img_q + TILE_BYTES;
@@ -195,9 +211,6 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
       // this wave's 32 keys x 64 queries: anything masked?  everything masked?
       const bool need_mask = CAUSAL && (row0 < wave_row0 + 31 - shift);
       const bool active = !CAUSAL || (row0 + BN - 1 >= wave_row0 - shift);
-      // per tile-row statistics: LSE (role 0) or delta (role 1) of the (b, query head) row; out of range -> 0
-      const long long so = (long long)(b * p.H + hr * G + g) * p.Nq;
-      auto st_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((role ? p.delta : p.lse) + so), 0, (unsigned)p.Nq * 4u, 0x00020000);
 
       bool stored = false;
       if (WS && role == 1 && !active) {              // a fully masked piece of a visited (block, tile) pair: zeros
@@ -277,6 +290,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
       }
       // WS: the 4 dS stores of this tile are the wave's YOUNGEST vector-memory operations (vmcnt counts stores and retires in
       // issue order): leave them in flight across the barrier — everything older, the LDS-DMA pieces of tile it+1 included, is done
+      next_tile();
       if (WS && stored) {
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         st_next = st_next + 1 == NSTAGE ? 0 : st_next + 1;

@@ -93,6 +93,20 @@ def trace(variant, cfg):
         if m.any():
             bhs = (t[m, 7] >> 32)
             print(f"  XCC{x}: WGs {m.sum()} heads {len(np.unique(bhs))} (bh%8 in {sorted(set((bhs % 8).tolist()))}) first start {st[m].min()} last end {en[m].max()} mean first-16 start {np.sort(st[m])[:32].mean():.0f}")
+    # real time (s_memrealtime, 100 MHz): per XCC the shader clock its workgroups saw and the busy time of its CUs — unequal XCC
+    # clocks under a shared power budget make the slowest XCC the launch's critical path (in-order round-robin dispatch gives
+    # every XCC the same number of workgroups)
+    rt_us = t[:, 6] / 100.0
+    per_x = []
+    for x in range(8):
+        m = xcc == x
+        if m.any():
+            cu_busy = np.array([rt_us[m & (cuid == c)].sum() for c in np.unique(cuid[m])])
+            per_x.append((x, float(np.median(mhz[m])), float(cu_busy.mean()), float(cu_busy.max())))
+    if per_x:
+        print("  real time per XCC: " + "  ".join(f"X{x}: {mz:.0f} MHz, CU busy {bm:.1f} us (max {bx:.1f})" for x, mz, bm, bx in per_x))
+        bm = np.array([a[2] for a in per_x])
+        print(f"  XCC busy-time spread: slowest / mean = {bm.max() / bm.mean():.3f}, slowest / fastest = {bm.max() / bm.min():.3f}")
     if os.environ.get("DUMP_CU"):
         for c in ucu[:: max(1, len(ucu) // 4)][:4]:
             m = np.where(cuid == c)[0]
