@@ -236,34 +236,29 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
             for (int e = 0; e < 4; ++e) stv[t][4 * g4 + e] = a[e];
           }
         X8 keep[2][2];                                  // WS: dS of both halves, stored behind the tile's last MFMA
-        // ---- GEMM-I for BOTH 32-row halves first: S (role 0) or dP (role 1).  16 MFMAs back to back; the element-wise work of
-        //      half 1 then has the GEMM-II MFMAs of half 0 to hide under (a wave issues in order: with the halves handled one
-        //      after the other the matrix pipe idled through every exp / multiply burst: pipe busy 0.35 of the launch)
-        f32x16 x[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+          // ---- GEMM-I over the 32 tile rows of half t: S (role 0) or dP (role 1) -----------------------------------
+          f32x16 x;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
+          for (int r = 0; r < 16; ++r) x[r] = 0.f;
 #pragma unroll
           for (int sl = 0; sl < DS; ++sl) {
             const int off = k_rd_base + t * 32 * (D * 2) + (((2 * sl + hi) ^ k_rd_swz) << 4);
-            x[t] = E::mfma(__builtin_bit_cast(X8, lds_read_b128(img1, off)), rf[sl], x[t]);
+            x = E::mfma(__builtin_bit_cast(X8, lds_read_b128(img1, off)), rf[sl], x);
           }
-        }
-        X8 pkk[2][2];
-        auto elementwise = [&](int t) {
-          X8 (&pk)[2] = pkk[t];
+          X8 pk[2];
           if (role == 0) {
             if (need_mask) {
               const int limq = my_row - shift - row0 - 4 * hi;     // query offsets below this do not see the lane's key
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int qo = 32 * t + (r & 3) + 8 * (r >> 2);
-                if (qo < limq) x[t][r] = -INFINITY;
+                if (qo < limq) x[r] = -INFINITY;
               }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pk[r >> 3][r & 7] = (T)fast_exp2(fmaf(x[t][r], sc, -stv[t][r] * 1.4426950408889634f));
+            for (int r = 0; r < 16; ++r) pk[r >> 3][r & 7] = (T)fast_exp2(fmaf(x[r], sc, -stv[t][r] * 1.4426950408889634f));
             // hand P to the role-1 wave of this key group (it reads it in the next iteration)
 #pragma unroll
             for (int j = 0; j < 2; ++j) lds_write_b128(px, (t * 2 + j) * 1024 + lane * 16, __builtin_bit_cast(u32x4, pk[j]));
@@ -272,15 +267,10 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) pp[j] = __builtin_bit_cast(X8, lds_read_b128(px, (t * 2 + j) * 1024 + lane * 16));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pk[r >> 3][r & 7] = (T)((float)pp[r >> 3][r & 7] * (x[t][r] - stv[t][r]));
+            for (int r = 0; r < 16; ++r) pk[r >> 3][r & 7] = (T)((float)pp[r >> 3][r & 7] * (x[r] - stv[t][r]));
             if (WS) { keep[t][0] = pk[0]; keep[t][1] = pk[1]; }
           }
-        };
-        elementwise(0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          // ---- GEMM-II for the two 16-row slots of half t: dV^T += dO^T . P  /  dK^T += Q^T . dS; half 1's element-wise work
-          //      is issued between the MFMAs of half 0
+          // ---- GEMM-II for the two 16-row slots of this half: dV^T += dO^T . P  /  dK^T += Q^T . dS ----------------
 #pragma unroll
           for (int sl = 2 * t; sl < 2 * t + 2; ++sl)
 #pragma unroll
@@ -289,9 +279,8 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
               const s16x4 lo = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b1 + ((c ^ tr_s1) << 4));
               const s16x4 hh = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b2 + ((c ^ tr_s2) << 4));
               const s16x8 vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
-              acc[d] = E::mfma(__builtin_bit_cast(X8, vf), pkk[t][sl - 2 * t], acc[d]);
+              acc[d] = E::mfma(__builtin_bit_cast(X8, vf), pk[sl - 2 * t], acc[d]);
             }
-          if (t == 0) elementwise(1);
         }
         if (WS && role == 1) {
           ws_store(g, row0, keep[0]);
