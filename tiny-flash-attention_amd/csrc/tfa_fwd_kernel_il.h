@@ -46,88 +46,19 @@ constexpr int VF_IL_KSPLIT = 1 << 25;    // small non-causal grids: the 8 waves 
                                          // to group 0 through LDS at the end.  Two waves per SIMD where 128-row workgroups alone would leave one.
 constexpr int VF_IL_IDLE = 1 << 26;      // waves whose 32 rows all lie behind the last query row skip the tile work (decode-like problems: one
                                          // query block with one valid wave).  Its own instantiation: the flag costs the causal headline 0.5 %
-#ifndef TFA_IL_DECODE_NT
-#define TFA_IL_DECODE_NT 1               // decode instantiations (VF_IL_IDLE: one query block per head): K/V tiles nobody else reads are
+constexpr bool IL_DECODE_NT = true;      // decode instantiations (VF_IL_IDLE: one query block per head): K/V tiles nobody else reads are
                                          // loaded non-temporal — MHA decode 6.3 -> 6.6 TB/s, packed GQA 5.9 -> 7.0 TB/s (profiles/r02_decode_nt_ab.txt)
-#endif
+constexpr int IL_OSTORE_AUX = 2;         // cache policy of the O row stores: nt — O is written once and never re-read, the XCD's L2 is better spent on
+                                         // the K/V tiles every query block of the head re-reads (cfg3: +1.8 %, others +-0; profiles/r02_ostore_ab.txt)
 constexpr int VF_IL_WINDOWED = 1 << 24;  // K/V tiles through per-tile descriptors (rsrc_at): a (b,h) slice may exceed 2 GiB.  ~6 % slower (a fresh
                                          // descriptor per tile: ~14 SALU + the SGPR->VMEM wait states), so only launched when needed
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
                                          // so the two waves of a SIMD never sit in an LDS-DMA issue stall at the same time
 
-// ---- O accumulators in hand-pinned registers v[192:255] ---------------------------------------------------------
-// The kernel is compiled with amdgpu_num_vgpr(96) (LLVM doubles the request on gfx90a+: 192 unified registers): the register allocator owns v0..v191 and never sees O.  With O as
-// ordinary SSA values (builtin MFMA) the allocator split the 64-register live range around the loop and copied all of O
-// between two register sets every iteration; with "+a" (AGPR) operands it halves the VGPR budget to 128.  Every access
-// to O is therefore inline asm naming the physical registers: d tile i lives in v[192+16i : 207+16i].
-#define TFA_O_CLOB0 "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207"
-#define TFA_O_CLOB1 "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223"
-#define TFA_O_CLOB2 "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239"
-#define TFA_O_CLOB3 "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
-#define TFA_O_LIST01 "192,193,194,195,196,197,198,199,200,201,202,203,204,205,206,207,208,209,210,211,212,213,214,215,216,217,218,219,220,221,222,223"
-#define TFA_O_LIST23 "224,225,226,227,228,229,230,231,232,233,234,235,236,237,238,239,240,241,242,243,244,245,246,247,248,249,250,251,252,253,254,255"
-template <typename T> struct MfmaName;
-template <> struct MfmaName<__bf16> { static constexpr bool bf = true; };
-template <> struct MfmaName<_Float16> { static constexpr bool bf = false; };
+}  // namespace tfa
+#include "tfa_fwd_il_regs.h"
 
-// O[d tile DI] += A.B.  A VALU write of an A/B operand needs 2 wait states before an MFMA reads it and the compiler
-// cannot see that this asm is an MFMA: every caller packs P at least one whole MFMA slot before the MFMA that reads it.
-#define TFA_PV_CASE(DI, LO, HI, CLOB)                                                                                  \
-  if constexpr (DI == (LO - 192) / 16) {                                                                               \
-    if constexpr (MfmaName<T>::bf)                                                                                     \
-      asm volatile("v_mfma_f32_32x32x16_bf16 v[" #LO ":" #HI "], %0, %1, v[" #LO ":" #HI "]" ::"v"(a), "v"(b) : CLOB); \
-    else                                                                                                               \
-      asm volatile("v_mfma_f32_32x32x16_f16 v[" #LO ":" #HI "], %0, %1, v[" #LO ":" #HI "]" ::"v"(a), "v"(b) : CLOB);  \
-  }
-template <typename T, int DI, typename X8> static __device__ __forceinline__ void o_mfma(X8 a, X8 b) {
-  TFA_PV_CASE(DI, 192, 207, TFA_O_CLOB0)
-  TFA_PV_CASE(DI, 208, 223, TFA_O_CLOB1)
-  TFA_PV_CASE(DI, 224, 239, TFA_O_CLOB2)
-  TFA_PV_CASE(DI, 240, 255, TFA_O_CLOB3)
-}
-// S accumulators of the fast path: the MFMA is inline asm only so that it stays the FIRST instruction of its slot (a
-// builtin MFMA may be scheduled behind the slot's VALU work, which then delays the matrix pipe instead of hiding under
-// it).  The results are first read by VALU code at least two MFMA issues later (row max in part 2), which covers
-// the MFMA-write -> VALU-read distance the compiler cannot insert for an asm.
-template <typename T, typename X8> static __device__ __forceinline__ void s_mfma0(f32x16& c, X8 a, X8 b) {
-  if constexpr (MfmaName<T>::bf) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
-  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
-}
-template <typename T, typename X8> static __device__ __forceinline__ void s_mfma(f32x16& c, X8 a, X8 b) {
-  if constexpr (MfmaName<T>::bf) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-template <typename T, typename X8> static __device__ __forceinline__ void o_mfma_d(int d, X8 a, X8 b) {   // d folds to a constant
-  if (d == 0) o_mfma<T, 0>(a, b);
-  else if (d == 1) o_mfma<T, 1>(a, b);
-  else if (d == 2) o_mfma<T, 2>(a, b);
-  else o_mfma<T, 3>(a, b);
-}
-template <int DT> static __device__ __forceinline__ void o_zero() {
-  asm volatile(".irp r," TFA_O_LIST01 "\n\tv_mov_b32 v[\\r], 0\n\t.endr" ::: TFA_O_CLOB0, TFA_O_CLOB1);
-  if constexpr (DT == 4) asm volatile(".irp r," TFA_O_LIST23 "\n\tv_mov_b32 v[\\r], 0\n\t.endr" ::: TFA_O_CLOB2, TFA_O_CLOB3);
-}
-// O *= alpha (per lane); the leading s_nops cover the MFMA-write -> VALU-read distance (cold path)
-template <int DT> static __device__ __forceinline__ void o_scale(float alpha) {
-  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t.irp r," TFA_O_LIST01 "\n\tv_mul_f32 v[\\r], v[\\r], %0\n\t.endr" ::"v"(alpha) : TFA_O_CLOB0, TFA_O_CLOB1);
-  if constexpr (DT == 4)
-    asm volatile(".irp r," TFA_O_LIST23 "\n\tv_mul_f32 v[\\r], v[\\r], %0\n\t.endr" ::"v"(alpha) : TFA_O_CLOB2, TFA_O_CLOB3);
-}
-// out[r] = O[d tile DI][r] * inv
-#define TFA_OR(B, K) "v_mul_f32 %" #K ", v[" #B "+" #K "], %16\n\t"
-#define TFA_OREAD_CASE(DI, B)                                                                                          \
-  if constexpr (DI == (B - 192) / 16)                                                                                  \
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t" TFA_OR(B, 0) TFA_OR(B, 1) TFA_OR(B, 2) TFA_OR(B, 3) TFA_OR(B, 4) TFA_OR(B, 5) TFA_OR(B, 6)       \
-                 TFA_OR(B, 7) TFA_OR(B, 8) TFA_OR(B, 9) TFA_OR(B, 10) TFA_OR(B, 11) TFA_OR(B, 12) TFA_OR(B, 13) TFA_OR(B, 14) TFA_OR(B, 15) \
-                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),  \
-                   "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])\
-                 : "v"(inv));
-template <int DI> static __device__ __forceinline__ void o_read(float (&o)[16], float inv) {
-  TFA_OREAD_CASE(DI, 192)
-  TFA_OREAD_CASE(DI, 208)
-  TFA_OREAD_CASE(DI, 224)
-  TFA_OREAD_CASE(DI, 240)
-}
+namespace tfa {
 
 // AB: timing-only ablation bits of the fast path (results are wrong when set; tools/ablate_il.py)
 constexpr int ILAB_NOEXP = 1, ILAB_NODMA = 2, ILAB_NOBARRIER = 4, ILAB_NOMAX = 8, ILAB_NOQK = 16, ILAB_NOPV = 32, ILAB_NOKREAD = 64, ILAB_NOVREAD = 128;
@@ -150,39 +81,21 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   constexpr int DT = D / 32;
   constexpr int N1 = 2 * DS;                       // QK^T MFMAs per tile
   constexpr int N2 = 4 * DT;                       // PV MFMAs per tile
-#ifndef TFA_IL_NE1
-#define TFA_IL_NE1 21
-#endif
-#ifndef TFA_IL_PF
-#define TFA_IL_PF 2
-#endif
-  constexpr int NE1 = TFA_IL_NE1;                  // softmax elements (of 32 per lane) summed/packed during part 1
-  constexpr int PFK = TFA_IL_PF, PFV = TFA_IL_PF;  // fragment read-ahead, in MFMAs
-#ifndef TFA_IL_UNIFORM
-#define TFA_IL_UNIFORM 0
-#endif
-#ifndef TFA_IL_ASMQK
-#define TFA_IL_ASMQK 0
-#endif
+  // (settled by same-process A/Bs, all within +-0.7 %: read-ahead 3 or 4, 19 or 24 elements in part 1, a uniform element-to-slot
+  //  map, inline-asm QK^T MFMAs, one key block after the other in part 1, the causal wave permutation — profiles/r02_*_ab.txt)
+  constexpr int NE1 = 21;                          // softmax elements (of 32 per lane) summed/packed during part 1
+  constexpr int PFK = 2, PFV = 2;                  // fragment read-ahead, in MFMAs
   // MFMA slot (0..N1+N2-1) in which softmax element e (0..31) is summed and packed; its exp2 is issued one slot and its
   // scale/subtract two slots earlier.  P slot s (elements 8s..8s+7) feeds PV MFMAs N1+DT*s.., so it must be packed in
   // an EARLIER slot than N1+DT*s (also the distance the asm MFMA needs after a VALU write of its operand).
   auto slot_of_elem = [](int e) constexpr -> int {
-#if TFA_IL_UNIFORM
-    return 1 + e * (N1 + 3 * DT - 1) / 32;           // evenly over the slots before the last P slot is consumed
-#else
     return 1 + (e < NE1 ? e * N1 / NE1 : N1 + (e - NE1) * (3 * DT - 1) / (32 - NE1));
-#endif
   };
   static_assert(slot_of_elem(7) < N1 && slot_of_elem(15) < N1 + DT && slot_of_elem(23) < N1 + 2 * DT && slot_of_elem(31) < N1 + 3 * DT,
                 "a P slot is packed too late for the PV MFMA that reads it");
-#ifndef TFA_IL_QKSPLIT
-#define TFA_IL_QKSPLIT 0
-#endif
-  // QK^T MFMA i works on key block KT(i) with k-slot KS(i): interleaved (0) or one key block after the other (1)
-  constexpr bool QKSPLIT = TFA_IL_QKSPLIT;
-#define KT(i) (QKSPLIT ? (i) / DS : (i) & 1)
-#define KS(i) (QKSPLIT ? (i) % DS : (i) >> 1)
+  // QK^T MFMA i works on key block KT(i) with k-slot KS(i): the two key blocks alternate
+#define KT(i) ((i) & 1)
+#define KS(i) ((i) >> 1)
   constexpr bool PAIR = CAUSAL && (VF & VF_PAIR);
   static_assert(PPW >= 1 && PPW * NWG == PIECES, "tile does not split into whole DMA pieces per wave");
 
@@ -199,12 +112,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = KSPLIT ? wave_id % NWG : wave_id;   // index inside the query block: rows, DMA pieces, epilogue slice
-#ifndef TFA_IL_WPERM
-#define TFA_IL_WPERM 0
-#endif
-  // the 32-row block of a wave.  Causal, 8 waves: waves w and w+4 share a SIMD and the diagonal block gives row block r
-  // ceil((r+1)/2) tiles — with the identity the SIMDs get 4,4,6,6 tiles, with {0,1,2,3,7,6,5,4} they get 5,4,5,4
-  const int wrow = (TFA_IL_WPERM && CAUSAL && NW == 8 && wave >= 4) ? 11 - wave : wave;
+  // the 32-row block of a wave (a permutation that evens out the diagonal block's tiles per SIMD — {0,1,2,3,7,6,5,4} — measured
+  // neutral: the per-tile barrier sets the diagonal's wall time whatever the map; profiles/r02_window_ab2.txt)
+  const int wrow = wave;
   const int qi = lane & 31;
   const int hi = lane >> 5;
 
@@ -274,12 +184,12 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const bool kv_private = p.H == p.Hk;             // (query heads that share a K/V head share its tiles in L2: no streaming hint then)
   auto dma_k1 = [&](int t, int buf, int i) {
     if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(kbase, k_bytes, (unsigned long long)t * (unsigned)k_tile_stride), lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i]);
-    else if ((VF & VF_IL_IDLE) && TFA_IL_DECODE_NT && kv_private) lds_dma16_m0_nt(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
+    else if ((VF & VF_IL_IDLE) && IL_DECODE_NT && kv_private) lds_dma16_m0_nt(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
     else lds_dma16_m0(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
   };
   auto dma_v1 = [&](int t, int buf, int i) {
     if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(vbase, v_bytes, (unsigned long long)t * (unsigned)v_tile_stride), lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i]);
-    else if ((VF & VF_IL_IDLE) && TFA_IL_DECODE_NT && kv_private) lds_dma16_m0_nt(v_rs, lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i] + t * v_tile_stride);
+    else if ((VF & VF_IL_IDLE) && IL_DECODE_NT && kv_private) lds_dma16_m0_nt(v_rs, lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i] + t * v_tile_stride);
     else lds_dma16_m0(v_rs, lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i] + t * v_tile_stride);
   };
   auto dma_k = [&](int t, int buf) {
@@ -331,10 +241,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     const int qoff = ((WIN ? 0 : q0x) + wrow * 32 + qi) * (int)p.qs_n * 2 + hi * 16;
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
-#ifndef TFA_IL_QLOAD_AUX
-#define TFA_IL_QLOAD_AUX 0
-#endif
-      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, (2 * s + hi) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB, 0, TFA_IL_QLOAD_AUX);
+      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, (2 * s + hi) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB, 0, 0);
       qf[s] = __builtin_bit_cast(X8, t);
     }
   };
@@ -467,373 +374,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       return __builtin_bit_cast(X8, w);
     };
 
-    // ---- prologue: K(0), V(0), K(1) by DMA, Q fragments, S(0) and its row max -------------------------
-    if (SEAM && seam_in) { /* the previous pass streamed K(0), K(1), V(0) and asked for Q */ }
-    else if (!PREF || pass == 0) issue_prologue(mb, true);      // (with PREF the previous pass already asked for this block)
-    // this pass continues its tile stream into the next one when there is one and the buffer parities line up (nt even)
-    const bool seam = SEAM && (pass + 1 < npass) && ((nt & 1) == 0) && nt >= 2;
-    o_zero<DT>();
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));
-    asm volatile("s_barrier" ::: "memory");
-    if (p.trace && pass == tr_pass) t_pro = __builtin_amdgcn_s_memtime();
-
-    // tiles this wave computes: 0 .. nact-1 (causal: the waves of a block stop at different tiles)
-    const int nact = (wave_last_tile + 1 < nt_own) ? (wave_last_tile + 1) : nt_own;
-    // A wave whose 32 rows all lie behind the last query row computes nothing: decode-like problems have one valid wave per
-    // block, and the tile rate — hence the K/V streaming rate — is then that one wave's.  (A separate flag, not a smaller
-    // nact: non-causal kernels keep nact == nt as a compile-time fact and lose 2 % without it.)
-    const bool idle_wave = (VF & VF_IL_IDLE) != 0 && wave_row0 >= p.Nq;
-    // first tile of this wave that needs masking (causal diagonal or ragged tail); nact if none
-    int fm = nact;
-    {
-      int first_g = 0x3fffffff;                            // first tile OF THE HEAD that needs a mask for this wave
-      if (p.Nk % BN) first_g = p.Nk / BN;
-      if (CAUSAL) {
-        const int c = pos_lo + shift + 1;                  // keys 0..c-1 are visible to every row of the wave
-        const int full = c > 0 ? c / BN : 0;               // tiles 0..full-1 need no mask
-        first_g = full < first_g ? full : first_g;
-      }
-      const int first = KSPLIT ? (first_g <= grp ? 0 : (first_g - grp + 1) >> 1) : first_g;   // ... in the wave's own tile numbering
-      fm = first < fm ? first : fm;
-    }
-
-    f32x16 sA[2], sB[2];
-    float mA = -INFINITY, mB = -INFINITY;
-    auto qk_burst = [&](int kbuf, int t, f32x16 (&s)[2], float& mout) {   // S(t) = K(t) Q^T from K buffer kbuf, masked, row max
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[tt][r] = 0.f;
-      const unsigned kb = kbuf * TILE_BYTES;
-#pragma unroll
-      for (int i = 0; i < N1; ++i) s[KT(i)] = E::mfma(k_frag_rt(kb, i), qf[KS(i)], s[KT(i)]);
-      if (needs_mask(t)) apply_mask(t, s);
-      float mx = s[0][0];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tt][r]);
-      mout = pair_max(mx);
-    };
-    if (nact > 0 && !idle_wave) {
-      qk_burst(0, 0, sA, mA);
-      mref = fmaxf(mref, mA * sc);                       // first re-base for free: O = 0 and l = 0 so far
-    }
-    // K buffer 0 is refilled with K(2) at the top of iteration 0: every wave must be done with K(0)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-#if defined(TFA_IL_TRACEWAIT)
-    // debug build: split the end of an iteration into (memory wait) and (barrier) and sum the cycles of each
-    auto iter_end = [&]() {
-      const unsigned long long a0 = __builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      const unsigned long long a1 = __builtin_amdgcn_s_memtime();
-      asm volatile("s_barrier" ::: "memory");
-      const unsigned long long a2 = __builtin_amdgcn_s_memtime();
-      tw_wait += a1 - a0;
-      tw_bar += a2 - a1;
-    };
-#else
-    auto iter_end = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-#endif
-
-    // ---- fast path: tile j (S in scur) -> O; S(j+1) and its row max -> snext, mnext.  One basic block. ---------
-    // PAR = j & 1: K(j+1) is in K buffer PAR^1, V(j) in V buffer PAR; K(j+2) -> K buffer PAR, V(j+1) -> V buffer PAR^1.
-    auto fused = [&](auto par_c, auto mask_c, int j, f32x16 (&scur)[2], f32x16 (&snext)[2], float& mnext) {
-      constexpr int PAR = decltype(par_c)::value;
-      constexpr bool MASK = decltype(mask_c)::value;   // tile j+1 is the wave's masked (diagonal / ragged) tile
-      constexpr bool SPREAD = (VF & VF_IL_DMASPREAD) != 0;
-      constexpr bool STAGGER = SPREAD && (VF & VF_IL_DMASTAGGER) != 0;
-      const bool late = STAGGER && wave >= NW / 2;
-      const bool issue_k = (j + 2 < nt) || seam;         // beyond the last tile: the next pass's K(0) / K(1)
-      const int tk = (j + 2 < nt) ? j + 2 : j + 2 - nt;
-      if (!SPREAD && !(AB & ILAB_NODMA)) {
-        if (issue_k) dma_k(tk, PAR);
-        dma_v(j + 1, PAR ^ 1);
-      }
-      const float msc = mref;
-      constexpr int KB = PAR ^ 1;
-      const char* vbp = vl + PAR * TILE_BYTES;
-      unsigned pw[16];
-      float xs[32];
-      X8 kf[N1], vf[N2];
-#pragma unroll
-      for (int i = 0; i < PFK; ++i) kf[i] = k_frag(KB, i);
-      // global MFMA slot g = 0..N1+N2-1; element e is summed/packed in slot SC(e), exponentiated in SC(e)-1, scaled in SC(e)-2
-      auto soft_slot = [&](int g) {
-#pragma unroll
-        for (int e = 0; e < 32; ++e) {
-          const int sc_e = slot_of_elem(e);
-          const int sb_e = sc_e - 1, sa_e = sc_e >= 2 ? sc_e - 2 : 0;
-          if (AB & ILAB_NOEXP) {
-            if (sc_e == g && (e & 1)) pw[e >> 1] = __builtin_bit_cast(unsigned, scur[e >> 4][e & 15]);
-          } else {
-            if (sa_e == g) st_fma(e, scur, msc, xs);
-            if (sb_e == g) st_exp(e, xs);
-            if (sc_e == g) st_sum(e, xs, l4, pw);
-          }
-        }
-      };
-      __builtin_amdgcn_sched_barrier(0);
-      // part 1
-#pragma unroll
-      for (int i = 0; i < N1; ++i) {
-        if (i + PFK < N1) kf[i + PFK] = ((AB & ILAB_NOKREAD) && i + PFK >= PFK) ? kf[(i + PFK) % PFK] : k_frag(KB, i + PFK);
-        else vf[i + PFK - N1] = v_frag(vbp, i + PFK - N1);
-        if (AB & ILAB_NOQK) {
-          if (i < 2) asm volatile("" : "+v"(snext[i]));
-        } else if (KS(i) == 0) {                           // first k-slot of a key block: C = 0 (inline constant)
-#if TFA_IL_ASMQK
-          s_mfma0<T>(snext[KT(i)], kf[i], qf[KS(i)]);
-#else
-          f32x16 z;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) z[r] = 0.f;
-          snext[KT(i)] = E::mfma(kf[i], qf[KS(i)], z);
-#endif
-        } else {
-#if TFA_IL_ASMQK
-          s_mfma<T>(snext[KT(i)], kf[i], qf[KS(i)]);
-#else
-          snext[KT(i)] = E::mfma(kf[i], qf[KS(i)], snext[KT(i)]);
-#endif
-        }
-        if (SPREAD && !(AB & ILAB_NODMA) && !(STAGGER && late)) {   // 2*PPW DMA pieces spread over the first MFMAs, one per MFMA
-          if (i < PPW) dma_v1(j + 1, PAR ^ 1, i);
-          else if (i < 2 * PPW) { if (issue_k) dma_k1(tk, PAR, i - PPW); }
-        }
-        soft_slot(i);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (MASK) {                                     // S(j+1) is complete (MFMA results: the s_nop covers the read distance)
-#if TFA_IL_ASMQK
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
-        apply_mask(j + 1, snext);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // part 2
-      float mx = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < N2; ++i) {
-        if (i + PFV < N2) vf[i + PFV] = (AB & ILAB_NOVREAD) ? vf[(i + PFV) % PFV] : v_frag(vbp, i + PFV);
-        if (!(AB & ILAB_NOPV)) o_mfma_d<T>(i % DT, vf[i], p_frag(pw, i / DT));
-        else asm volatile("" ::"v"(vf[i]), "v"(pw[(i / DT) * 4]), "v"(pw[(i / DT) * 4 + 1]), "v"(pw[(i / DT) * 4 + 2]), "v"(pw[(i / DT) * 4 + 3]));
-        if (STAGGER && late && !(AB & ILAB_NODMA)) {
-          if (i < PPW) dma_v1(j + 1, PAR ^ 1, i);
-          else if (i < 2 * PPW) { if (issue_k) dma_k1(tk, PAR, i - PPW); }
-        }
-        soft_slot(N1 + i);
-#pragma unroll
-        for (int q = 0; q < 16; ++q)               // 16 pairs of S(j+1) values -> one v_max3 each
-          if (q * N2 / 16 == i && !(AB & ILAB_NOMAX)) {
-            mx = fmaxf(fmaxf(mx, snext[q >> 3][2 * (q & 7)]), snext[q >> 3][2 * (q & 7) + 1]);
-            asm volatile("" : "+v"(mx));
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      mnext = (AB & ILAB_NOMAX) ? snext[0][0] * 1e-30f : mx;   // this half-wave's 32 keys only (see rescale_if_needed)
-      if (AB & ILAB_NOBARRIER) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else iter_end();
-    };
-    // ---- slow path: any tile (masked, last, re-base needed).  S(j) is in scur, S(j+1) goes to snext ------------------
-    auto slow = [&](int j, f32x16 (&scur)[2], float mcur, f32x16 (&snext)[2], float& mnext) {
-      const int par = j & 1;
-      ++n_slow;
-      if (j + 2 < nt) dma_k(j + 2, par);
-      else if (seam) dma_k(j + 2 - nt, par);
-      if (j + 1 < nt) dma_v(j + 1, par ^ 1);
-      else if (seam) dma_v(0, par ^ 1);
-      rescale_if_needed(mcur);
-      const float msc = mref;
-      const char* vbp = vl + par * TILE_BYTES;
-      unsigned pw[16];
-      float ev_hold = 0.f;
-#pragma unroll
-      for (int e = 0; e < 32; ++e) soft_elem(e, scur, msc, l4, pw, ev_hold);
-#pragma unroll
-      for (int i = 0; i < N2; ++i) o_mfma_d<T>(i % DT, v_frag(vbp, i), p_frag(pw, i / DT));
-      if (j + 1 < nact) qk_burst(par ^ 1, j + 1, snext, mnext);
-      iter_end();
-    };
-
-    // S(j) lives in sA for even j and in sB for odd j, on both paths, so the paths alternate freely without copies.
-    // Tile j takes the fast path when tile j+1 exists and no row max of tile j has outgrown mref; if tile j+1 needs
-    // masking (at most the wave's last one or two tiles) the body with the mask between its two parts runs.
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    using MN = std::integral_constant<bool, false>;
-    using MY = std::integral_constant<bool, true>;
-    if (!idle_wave)
-#pragma nounroll
-    for (int j = 0; j < nact; j += 2) {
-      if (j + 1 < nact && !trigger(mA)) {
-        if (j + 1 < fm) fused(C0{}, MN{}, j, sA, sB, mB);
-        else fused(C0{}, MY{}, j, sA, sB, mB);
-      } else {
-        slow(j, sA, mA, sB, mB);
-      }
-      if (j + 1 >= nact) break;
-      if (j + 2 < nact && !trigger(mB)) {
-        if (j + 2 < fm) fused(C1{}, MN{}, j + 1, sB, sA, mA);
-        else fused(C1{}, MY{}, j + 1, sB, sA, mA);
-      } else {
-        slow(j + 1, sB, mB, sA, mA);
-      }
-    }
-#pragma nounroll
-    for (int j = idle_wave ? 0 : nact; j < nt; ++j) {    // tiles of the block this wave does not touch
-      if (j + 2 < nt) dma_k(j + 2, j & 1);
-      else if (seam) dma_k(j + 2 - nt, j & 1);
-      if (j + 1 < nt) dma_v(j + 1, (j & 1) ^ 1);
-      else if (seam) dma_v(0, (j & 1) ^ 1);
-      iter_end();
-    }
-    if (p.trace && pass == tr_pass) t_loop = __builtin_amdgcn_s_memtime();
-
-    // ---- epilogue ---------------------------------------------------------------------------
-    // every wave is past the last tile's barrier: the K/V buffers and qf are free -> ask for the next pass's first tiles
-    // and Q now, so that their latency hides behind the normalisation and the stores below
-    if (PREF && pass + 1 < npass) issue_prologue(block_of(pass + 1), true);
-    if (SEAM) { seam_in = seam; if (seam) issue_prologue(block_of(pass + 1), false); }   // Q only: K(0), K(1), V(0) are on chip
-    float l_tot = pair_sum((l4[0] + l4[1]) + (l4[2] + l4[3]));
-    float w0 = 1.f, w1 = 0.f;                          // KSPLIT: weights of this group's and the other group's partial result
-    const char* const dump = smem + 4 * TILE_BYTES;    // KSPLIT: group 1's (now idle) tile buffers carry its O to group 0
-    if constexpr (KSPLIT) {
-      // the two groups hold partial results over disjoint key sets: group 1 writes (m, l, O) — lane-private data, no
-      // transposition — and leaves; group 0 merges by the split-KV rule (tfa_merge.hip) while it reads its own O out
-      float* const ml = reinterpret_cast<float*>(smem + wave * (32 * D * 2)) + lane * 2;   // (in group 0's idle buffers)
-      if (grp == 1) {
-        ml[0] = mref; ml[1] = l_tot;
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-          float o[16];
-          if (d == 0) o_read<0>(o, 1.f); else if (d == 1) o_read<1>(o, 1.f); else if (d == 2) o_read<2>(o, 1.f); else o_read<3>(o, 1.f);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v4 = {o[4 * g + 0], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-            *reinterpret_cast<f32x4*>(const_cast<char*>(dump) + ((((wave * DT + d) << 2) + g) << 10) + lane * 16) = v4;
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (grp == 1) {
-        if (pass + 1 >= npass) return;
-        // paired causal blocks: group 0 still reads this group's buffers (the dump) and writes its own (epilogue slices);
-        // the next pass's first DMA pieces wait behind the barrier group 0 ends its epilogue with
-        asm volatile("s_barrier" ::: "memory");
-        continue;
-      }
-      const float m1 = ml[0], l1 = ml[1];
-      const float m = fmaxf(mref, m1);
-      w0 = (mref == -INFINITY) ? 0.f : fast_exp2(mref - m);
-      w1 = (m1 == -INFINITY) ? 0.f : fast_exp2(m1 - m);
-      l_tot = w0 * l_tot + w1 * l1;
-      mref = m;
-    }
-    const bool empty = !(l_tot > 0.f);
-    const float inv = empty ? 1.f : 1.f / l_tot;
-    // O[d tile d][0..15] of this lane, normalised (KSPLIT: merged with the other group's)
-    auto o_get = [&](int d, float (&o)[16]) {
-      const float f0 = inv * w0;
-      if (d == 0) o_read<0>(o, f0); else if (d == 1) o_read<1>(o, f0); else if (d == 2) o_read<2>(o, f0); else o_read<3>(o, f0);
-      if constexpr (KSPLIT) {
-        const float f1 = inv * w1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(dump + ((((wave * DT + d) << 2) + g) << 10) + lane * 16);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[4 * g + e] = fmaf(f1, x[e], o[4 * g + e]);
-        }
-      }
-    };
-    if (p.lse != nullptr && hi == 0 && my_row < p.Nq) {
-      const float lse = empty ? INFINITY : (mref + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
-      p.lse[(long long)bh * p.Nq + my_row] = lse;
-    }
-    if (F32OUT) {
-      float* obase = reinterpret_cast<float*>(p.o) + b * p.os_b + h * p.os_h;
-      auto o_rs = rsrc_at(obase, p.o_bytes, WIN ? (unsigned long long)q0 * (unsigned long long)p.os_n * 4ull : 0ull);
-      const int ooff = (my_row - (WIN ? q0 : 0)) * (int)p.os_n * 4 + hi * 16;
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        float o[16];
-        o_get(d, o);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v4 = {o[4 * g + 0], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, d * 32 + g * 8 + hi * 4 < p.dv ? ooff + (d * 32 + g * 8) * 4 : (int)TFA_OOB, 0, 0);
-        }
-      }
-    } else if (EPI) {
-      // A lane holds 4-element pieces of ONE row spread over 16 register groups: stored directly that is 16 eight-byte
-      // stores per lane, 32 different rows per instruction.  Instead the wave transposes its 32 x D tile through its own
-      // slice of the epilogue region (16-byte chunk index XOR row, as for K) and writes whole rows: 1 KiB contiguous per
-      // store instruction.  The region is separate from the tile buffers (which the next pass is already filling).
-      T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
-      auto o_rs = rsrc_at(obase, p.o_bytes, WIN ? (unsigned long long)q0 * (unsigned long long)p.os_n * 2ull : 0ull);
-      typedef __attribute__((ext_vector_type(4))) T t4;
-      // (the lane ids go through an empty asm so that none of the 24 addresses below is loop-invariant: hoisted out of
-      // the pass loop they would stay live across the main loop and spill)
-      int qix = qi, lanex = lane;
-      asm volatile("" : "+v"(qix), "+v"(lanex));
-      constexpr bool INPLACE = (VF & VF_IL_EPI_INPLACE) != 0;
-      static_assert(!INPLACE || !PREF, "in-place epilogue slices would be overwritten by the next pass's prefetch");
-      char* const ow = smem + (INPLACE ? 0 : 4 * TILE_BYTES) + wave * (32 * D * 2);
-      constexpr int CH = D / 8;                      // 16-byte chunks per row
-      const int osw = (CH == 16) ? (qix & 15) : (qix & 7);
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        float o[16];
-        o_get(d, o);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          t4 v4 = {(T)o[4 * g + 0], (T)o[4 * g + 1], (T)o[4 * g + 2], (T)o[4 * g + 3]};
-          const int c = d * 4 + g;
-          *reinterpret_cast<u32x2*>(ow + qix * (D * 2) + ((c ^ osw) << 4) + (lanex >> 5) * 8) = __builtin_bit_cast(u32x2, v4);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slice: no barrier needed
-      constexpr int RPI = 64 / CH;                   // rows per store instruction (4 at D=128, 8 at D=64)
-#pragma unroll
-      for (int i = 0; i < 32 / RPI; ++i) {
-        const int r = i * RPI + lanex / CH, cpos = lanex % CH;
-        const int c = cpos ^ ((CH == 16) ? (r & 15) : (r & 7));
-        u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
-#ifndef TFA_IL_OSTORE_AUX
-#define TFA_IL_OSTORE_AUX 2     // cache policy of the O row stores: nt — O is written once and never re-read, the XCD's L2 is better spent on
-                                // the K/V tiles every query block of the head re-reads (cfg3: +1.8 %, others +-0; profiles/r02_ostore_ab.txt)
-#endif
-        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 - (WIN ? q0 : 0) + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, TFA_IL_OSTORE_AUX);
-      }
-      if (INPLACE) {
-        // the next pass's first DMA pieces land in these buffers: every wave must have read its rows back
-        if (!KSPLIT && pass + 1 < npass) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (KSPLIT: below, every output type)
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by this wave's next epilogue only
-      }
-    } else {
-      T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
-      auto o_rs = rsrc_at(obase, p.o_bytes, WIN ? (unsigned long long)q0 * (unsigned long long)p.os_n * 2ull : 0ull);
-      const int ooff = (my_row - (WIN ? q0 : 0)) * (int)p.os_n * 2 + hi * 8;
-      typedef __attribute__((ext_vector_type(4))) T t4;
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        float o[16];
-        o_get(d, o);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          t4 v4 = {(T)o[4 * g + 0], (T)o[4 * g + 1], (T)o[4 * g + 2], (T)o[4 * g + 3]};
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, d * 32 + g * 8 + hi * 4 < p.dv ? ooff + (d * 32 + g * 8) * 2 : (int)TFA_OOB, 0, 0);
-        }
-      }
-    }
-    // KSPLIT, another pass to come: group 0 has read group 1's dump and its own epilogue slices — both live in tile buffers the
-    // next pass's first DMA pieces overwrite (group 1 waits at the matching barrier right behind the merge)
-    if (KSPLIT && pass + 1 < npass) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#include "tfa_fwd_il_pass_prologue.inc"
+#include "tfa_fwd_il_tile_loop.inc"
+#include "tfa_fwd_il_epilogue.inc"
   }
 
   if (p.trace) {
