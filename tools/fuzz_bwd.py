@@ -5,7 +5,7 @@ import argparse, math, os, random, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tiny_flash_attention_amd import ops
+from tiny_flash_attention_amd import _lib, ops
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=150)
@@ -32,7 +32,12 @@ for it in range(a.n):
     q, k, v, dout = mk(Nq, H), mk(Nk, Hk), mk(Nk, Hk), mk(Nq, H)
     sc = rng.choice([1.0 / math.sqrt(D), 0.05, 0.2])
     out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout)
-    dq, dk, dv = ops.flash_attn_bwd(q, k, v, out, lse, dout, causal, sc, layout=layout)
+    mode = rng.choice(["default", "default", "workspace", "split"])     # tfa_bwd's three forms (tests/test_bwd_gpu.py: MODES)
+    _lib.debug_bwd_split(mode == "split")
+    try:
+        dq, dk, dv = ops.flash_attn_bwd(q, k, v, out, lse, dout, causal, sc, layout=layout, workspace=True if mode == "workspace" else None)
+    finally:
+        _lib.debug_bwd_split(False)
     tr = (lambda t: t) if layout == "bhnd" else (lambda t: t.transpose(1, 2))
     qf, kf, vf = (tr(t).float().detach().requires_grad_(True) for t in (q, k, v))
     ke, ve = kf.repeat_interleave(H // Hk, 1), vf.repeat_interleave(H // Hk, 1)
@@ -53,6 +58,6 @@ for it in range(a.n):
             msg.append(f"{name} max|d|={d:.3e} > {bar:.3e}")
     if msg:
         bad += 1
-        print(f"FAIL B{B} H{H} Hk{Hk} Nq{Nq} Nk{Nk} D{D} {dt} causal={causal} {layout} sc={sc:.3f}: " + "; ".join(msg), flush=True)
+        print(f"FAIL B{B} H{H} Hk{Hk} Nq{Nq} Nk{Nk} D{D} {dt} causal={causal} {layout} {mode} sc={sc:.3f}: " + "; ".join(msg), flush=True)
 print(f"{a.n - bad}/{a.n} ok")
 sys.exit(1 if bad else 0)
