@@ -235,6 +235,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other configs, decode, backward: ~8 s)")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "bwd"],
                     help="fwd (default, the BASELINE metric) or bwd: a step is one tfa_bwd call")
+    ap.add_argument("--bwd-form", default="default", choices=["default", "split", "workspace"],
+                    help="bwd mode: tfa_bwd's form — default (7 GEMM units), split (dK and dV as two launches: round 2's 8 units), "
+                         "workspace (dS kept in scratch memory: 5 units)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -286,6 +289,10 @@ def main():
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         delta = torch.empty_like(lse)
         pb = ops.make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, causal, sc)
+        if args.bwd_form == "workspace":
+            bwd_ws = torch.empty((max(16, ops.bwd_workspace_bytes(pb)),), dtype=torch.uint8, device=dev)
+            pb.workspace, pb.workspace_bytes = bwd_ws.data_ptr(), bwd_ws.numel()
+        _lib.debug_bwd_split(args.bwd_form == "split")
         pbref = C.byref(pb)
 
     def step():
@@ -442,7 +449,7 @@ def main():
             "dtype": "bf16" if dtype == torch.bfloat16 else "f16",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: FlashAttention-2 {'backward (delta+dQ+dK+dV)' if bwd else 'forward'}, per-GPU B={B} H={H} N={N} D={D} "
+                "workload": f"{args.config}: FlashAttention-2 {'backward (' + args.bwd_form + ' form: delta + dQ + dK/dV)' if bwd else 'forward'}, per-GPU B={B} H={H} N={N} D={D} "
                             f"{'causal' if causal else 'full'}, q/k/v normal(0,0.5) resident in HBM, scale=1/sqrt(D)",
                 "global_batch": B * world,
                 "per_gpu_batch": B,
