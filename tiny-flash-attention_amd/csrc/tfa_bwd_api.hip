@@ -173,7 +173,8 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   m.grad = p->dk; m.gs_b = p->dk_stride[0]; m.gs_h = p->dk_stride[1]; m.gs_n = p->dk_stride[2];
   m.grad2 = p->dv; m.g2s_b = p->dv_stride[0]; m.g2s_h = p->dv_stride[1]; m.g2s_n = p->dv_stride[2];
   if (!slice_bytes(p->Nk, p->dk_stride[2], p->D, gsz, &m.g_bytes) || !slice_bytes(p->Nk, p->dv_stride[2], p->D, gsz, &m.g2_bytes)) return TFA_ERR_STRIDE;
-  m.nrb = (p->Nk + 127) / 128;
+  constexpr int kv_keys = 32 * TFA_BWD_KV_KG_OF(false);   // resident keys per workgroup of the fused launch
+  m.nrb = (p->Nk + kv_keys - 1) / kv_keys;
   const int64_t grid = (int64_t)p->B * p->Hk * m.nrb;
   if (grid >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
   hipError_t e;

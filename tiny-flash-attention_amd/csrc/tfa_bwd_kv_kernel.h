@@ -12,8 +12,9 @@
 //     iteration it:   role 0 works on tile it (writes P(it) into exchange buffer it&1),
 //                     role 1 works on tile it-1 (reads P(it-1) from buffer (it-1)&1);  LDS-DMA fills tile it+1.
 // Three tile stages of two images each (Q and dO, row-major with the u_swz XOR swizzle of tfa_bwd_kernel.h: one image
-// serves the b128 row reads of GEMM-I and the transpose reads of GEMM-II), 128 resident keys per workgroup (4 key groups x 2
-// roles = 8 waves), every layout the forward's (verified on hardware).  Deterministic: no atomics, fixed summation order.
+// serves the b128 row reads of GEMM-I and the transpose reads of GEMM-II), KG key groups x 2 roles per workgroup (KG = 6: 192
+// resident keys, twelve waves, three per SIMD — the default; KG = 4: eight waves, the workspace form), every layout the forward's
+// (verified on hardware).  Deterministic: no atomics, fixed summation order.
 // GQA: the streamed sequence runs over the G query heads of the K/V head, as in tfa_bwd_kernel.h.
 #pragma once
 #include "tfa_bwd_kernel.h"
@@ -25,23 +26,25 @@ namespace tfa {
 // GEMM instead of recomputing S and dP.  Every (128-key block, 64-query tile) pair this kernel visits is written completely
 // (fully masked 32-key pieces as zeros); pairs it does not visit are entirely above the causal diagonal and the consumer
 // never reads them.
-template <typename T, int D, bool CAUSAL, bool F32OUT, bool WS = false>
-__global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
+template <typename T, int D, bool CAUSAL, bool F32OUT, bool WS = false, int KG = 4>
+__global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const BArgs p) {
   using E = Elem<T>;
   using X8 = typename E::x8;
-  constexpr int NW = 8, KG = 4;
+  constexpr int NW = 2 * KG;                       // KG key groups x 2 roles (KG = 6: three waves per SIMD, 168 registers each)
+  constexpr int NDMA = 8;                          // waves that issue LDS-DMA pieces
+  static_assert(KG == 4 || (KG == 6 && !WS), "the workspace layout is blocked by 128 keys");
   constexpr int BMK = KG * 32;                     // resident keys per workgroup
   constexpr int BN = 64;                           // streamed query rows per tile
   constexpr int CPR = D / 8;
   constexpr int TILE_BYTES = BN * D * 2;
   constexpr int PIECES = TILE_BYTES / 1024;
-  constexpr int PPW = PIECES / NW;
+  constexpr int PPW = PIECES / NDMA;
   constexpr int DS = D / 16;
   constexpr int DT = D / 32;
   constexpr int NSTAGE = 3;
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // image 0: Q tile, image 1: dO tile
   constexpr int PX_BYTES = 32 * BN * 2;            // one key group's P tile, 16 bit
-  static_assert(PPW >= 1 && PPW * NW == PIECES, "");
+  static_assert(PPW >= 1 && PPW * NDMA == PIECES, "");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -50,8 +53,8 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wave & 3;                         // key group: rows r0 + 32*kg ..
-  const int role = wave >> 2;                      // 0: S, P, dV     1: dP, dS, dK
+  const int kg = wave % KG;                        // key group: rows r0 + 32*kg ..
+  const int role = wave / KG;                      // 0: S, P, dV     1: dP, dS, dK
   const int qi = lane & 31;
   const int hi = lane >> 5;
 
@@ -112,6 +115,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
   auto q_rs = head_rsrc(p.q, 0), do_rs = head_rsrc(p.dout, 0);
   int jt_d = t_begin, g_d = 0;                     // position of the NEXT tile to request
   auto dma_next = [&](int stage) {
+    if (KG != 4 && wave >= NDMA) return;             // (KG = 6: the tile's pieces are issued by the first eight waves)
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
       lds_dma16_m0(q_rs, lds_base + stage * STAGE_BYTES + (wave * PPW + i) * 1024, src[0][i] + jt_d * tile_stride[0]);
@@ -225,9 +229,10 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
       }
       if (active) {
         // statistics of the 64 tile rows first (both halves): no load is issued between the dS stores below and the barrier
+        // (WS: both halves up front — no load may be issued between the dS stores and the barrier; otherwise per half: 16 live
+        //  registers fewer, which the three-waves-per-SIMD form needs)
         float stv[2][16];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
+        auto load_stats = [&](int t) {
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const int q = row0 + 32 * t + 8 * g4 + 4 * hi;
@@ -235,10 +240,13 @@ __global__ __launch_bounds__(512, 2) void bwd_kv_kernel(const BArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) stv[t][4 * g4 + e] = a[e];
           }
+        };
+        if (WS) { load_stats(0); load_stats(1); }
         X8 keep[2][2];                                  // WS: dS of both halves, stored behind the tile's last MFMA
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           // ---- GEMM-I over the 32 tile rows of half t: S (role 0) or dP (role 1) -----------------------------------
+          if (!WS) load_stats(t);
           f32x16 x;
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[r] = 0.f;

@@ -6,6 +6,13 @@
 #include "tfa_bwd_dq_kernel.h"
 #include "tfa_host_util.h"
 
+// key groups (32 resident keys each) per workgroup of the fused dK/dV kernel: 4 (eight waves, two per SIMD) or 6 (twelve waves,
+// three per SIMD, 168 registers each); the workspace form is blocked by 128 keys and stays at 4
+#ifndef TFA_BWD_KV_KG
+#define TFA_BWD_KV_KG 6
+#endif
+#define TFA_BWD_KV_KG_OF(WS) ((WS) ? 4 : TFA_BWD_KV_KG)
+
 namespace tfa {
 template <typename T, int D>
 hipError_t launch_bwd(const BArgs& a, int mode, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);
