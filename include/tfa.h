@@ -66,8 +66,8 @@ enum tfa_status {
   TFA_OK = 0,
   TFA_ERR_NULL = -1,          /* a required pointer is NULL */
   TFA_ERR_DTYPE = -2,         /* dtype not in {F16,BF16}; out_dtype not in {dtype,F32} */
-  TFA_ERR_HEAD_DIM = -3,      /* forward, split-KV: D not a multiple of 8 in [8,256]; merge: not a multiple of 4 in [4,256];
-                               * backward, TFA_FWD_EXACT_MAX: not a multiple of 8 in [8,128] */
+  TFA_ERR_HEAD_DIM = -3,      /* forward, split-KV, backward: D not a multiple of 8 in [8,256]; merge: not a multiple of 4 in [4,256];
+                               * TFA_FWD_EXACT_MAX: not a multiple of 8 in [8,128] */
   TFA_ERR_SHAPE = -4,         /* B,H,Hk,Nq,Nk <= 0 or H % Hk != 0 */
   TFA_ERR_STRIDE = -5,        /* a stride is negative, not 16-byte aligned, rows overlap, or 768 rows of a (b,h) slice span 2 GiB
                                * (tfa_fwd with D <= 128 switches to per-block / per-tile descriptor windows when a slice is larger,
@@ -226,6 +226,7 @@ typedef struct tfa_bwd_params {
 
 /* Launch the backward on `stream` (asynchronous): delta, dQ (S, dP, dQ: 3 GEMM units), then dK and dV in ONE launch that computes S and
  * dP once each (4 units; tfa_bwd_kv_kernel.h); with tfa_bwd_params::workspace: delta, dK/dV (which also writes dS), dQ = dS.K (1 unit).
+ * Head dims 136..256: three single-gradient launches (dQ, dK, dV) of the 256-wide kernel, one wave per SIMD.
  * Deterministic: no atomics, fixed summation order. */
 int tfa_bwd(const tfa_bwd_params* p, void* stream);
 /* Debug / A-B (per thread): on != 0 makes tfa_bwd run dK and dV as two single-gradient launches (S computed twice: the form of

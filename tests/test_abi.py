@@ -374,8 +374,9 @@ def test_bwd_descriptor_validation_without_gpu():
     assert L.tfa_bwd_plan(C.byref(_bwd_params())) == 0
     assert L.tfa_bwd_plan(C.byref(_bwd_params(grad_dtype=_lib.TFA_F32))) == 0          # fp32 gradients (debug path)
     assert L.tfa_bwd_plan(C.byref(_bwd_params(dtype=_lib.TFA_BF16, grad_dtype=_lib.TFA_F16))) == -2
-    assert L.tfa_bwd_plan(C.byref(_bwd_params(D=96))) == 0                              # any multiple of 8 up to 128
-    assert L.tfa_bwd_plan(C.byref(_bwd_params(D=100))) == -3 and L.tfa_bwd_plan(C.byref(_bwd_params(D=192))) == -3
+    assert L.tfa_bwd_plan(C.byref(_bwd_params(D=96))) == 0                              # any multiple of 8 up to 256
+    assert L.tfa_bwd_plan(C.byref(_bwd_params(D=192))) == 0 and L.tfa_bwd_plan(C.byref(_bwd_params(D=256))) == 0
+    assert L.tfa_bwd_plan(C.byref(_bwd_params(D=100))) == -3 and L.tfa_bwd_plan(C.byref(_bwd_params(D=264))) == -3
     assert L.tfa_bwd_plan(C.byref(_bwd_params(H=4, Hk=3))) == -4
     p = _bwd_params(); p.delta = None
     assert L.tfa_bwd_plan(C.byref(p)) == -1

@@ -101,6 +101,11 @@ BWD_SHAPES = [
     (torch.bfloat16, 1, 2, 2, 300, 300, 96, True),       # head dims inside the 128- and 64-wide kernels (columns beyond D read as zeros)
     (torch.float16, 2, 2, 1, 200, 333, 32, False),
     (torch.bfloat16, 1, 1, 1, 130, 130, 72, True),
+    # head dims above 128 (the reference's buckets 160 / 192 / 224 / 256, static_switch.h:39-66): the 256-wide single-gradient launches
+    (torch.bfloat16, 1, 2, 2, 384, 384, 256, True),
+    (torch.float16, 2, 4, 2, 200, 333, 160, True),       # GQA, ragged, bottom-right causal
+    (torch.bfloat16, 1, 2, 1, 300, 130, 192, False),     # MQA, Nq > Nk
+    (torch.float16, 1, 1, 1, 513, 513, 224, True),
 ]
 
 

@@ -13,6 +13,8 @@ template <> hipError_t launch_bwd<__bf16, 64>(const BArgs&, int, int, bool, bool
 template <> hipError_t launch_bwd<__bf16, 128>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_bwd<_Float16, 64>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_bwd<_Float16, 128>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd<__bf16, 256>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
+template <> hipError_t launch_bwd<_Float16, 256>(const BArgs&, int, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_bwd_kv<__bf16, 64>(const BArgs&, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_bwd_kv<__bf16, 128>(const BArgs&, int, bool, bool, hipStream_t, bool);
 template <> hipError_t launch_bwd_kv<_Float16, 64>(const BArgs&, int, bool, bool, hipStream_t, bool);
@@ -25,6 +27,8 @@ template <> hipError_t launch_delta<__bf16, 64>(const void*, const void*, float*
 template <> hipError_t launch_delta<__bf16, 128>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
 template <> hipError_t launch_delta<_Float16, 64>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
 template <> hipError_t launch_delta<_Float16, 128>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
+template <> hipError_t launch_delta<__bf16, 256>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
+template <> hipError_t launch_delta<_Float16, 256>(const void*, const void*, float*, const long long*, const long long*, int, int, long long, int, hipStream_t, bool);
 }  // namespace tfa
 
 namespace {
@@ -68,7 +72,7 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   if (!p->q || !p->k || !p->v || !p->out || !p->dout || !p->lse || !p->dq || !p->dk || !p->dv || !p->delta) return TFA_ERR_NULL;
   if (p->dtype != TFA_F16 && p->dtype != TFA_BF16) return TFA_ERR_DTYPE;
   if (p->grad_dtype != p->dtype && p->grad_dtype != TFA_F32) return TFA_ERR_DTYPE;
-  if (p->D < 8 || p->D > 128 || (p->D % 8) != 0) return TFA_ERR_HEAD_DIM;   // kernels are 64 and 128 wide; BArgs::dv = the valid part
+  if (p->D < 8 || p->D > 256 || (p->D % 8) != 0) return TFA_ERR_HEAD_DIM;   // kernels are 64, 128 and 256 wide; BArgs::dv = the valid part
   if (p->B <= 0 || p->H <= 0 || p->Hk <= 0 || p->Nq <= 0 || p->Nk <= 0 || p->H % p->Hk != 0) return TFA_ERR_SHAPE;
   if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
   const int esz = 2, gsz = (p->grad_dtype == TFA_F32) ? 4 : 2;
@@ -94,6 +98,7 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   a.B = p->B; a.H = p->H; a.Hk = p->Hk; a.Nq = p->Nq; a.Nk = p->Nk;
   a.dv = p->D;
   const bool wide = p->D > 64;
+  const bool wide256 = p->D > 128;          // head dims 136..256: one wave per SIMD, 128-row resident blocks, three single-gradient launches
   a.scale = p->softmax_scale;
   a.scale_log2 = p->softmax_scale * 1.4426950408889634f;
   const bool causal = p->is_causal != 0, f32 = p->grad_dtype == TFA_F32;
@@ -103,14 +108,17 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
     tfa::BArgs m = a;
     m.grad = grad; m.gs_b = gst[0]; m.gs_h = gst[1]; m.gs_n = gst[2];
     if (!slice_bytes(n_res, gst[2], p->D, gsz, &m.g_bytes)) return TFA_ERR_STRIDE;
-    m.nrb = (n_res + 255) / 256;
+    const int res_rows = wide256 ? 128 : 256;
+    m.nrb = (n_res + res_rows - 1) / res_rows;
     const int64_t grid = (int64_t)p->B * h_res * m.nrb;
     if (grid >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
     hipError_t e;
     if (p->dtype == TFA_BF16)
-      e = wide ? tfa::launch_bwd<__bf16, 128>(m, mode, (int)grid, causal, f32, s, dry) : tfa::launch_bwd<__bf16, 64>(m, mode, (int)grid, causal, f32, s, dry);
+      e = wide256 ? tfa::launch_bwd<__bf16, 256>(m, mode, (int)grid, causal, f32, s, dry)
+          : wide  ? tfa::launch_bwd<__bf16, 128>(m, mode, (int)grid, causal, f32, s, dry) : tfa::launch_bwd<__bf16, 64>(m, mode, (int)grid, causal, f32, s, dry);
     else
-      e = wide ? tfa::launch_bwd<_Float16, 128>(m, mode, (int)grid, causal, f32, s, dry) : tfa::launch_bwd<_Float16, 64>(m, mode, (int)grid, causal, f32, s, dry);
+      e = wide256 ? tfa::launch_bwd<_Float16, 256>(m, mode, (int)grid, causal, f32, s, dry)
+          : wide  ? tfa::launch_bwd<_Float16, 128>(m, mode, (int)grid, causal, f32, s, dry) : tfa::launch_bwd<_Float16, 64>(m, mode, (int)grid, causal, f32, s, dry);
     return (int)e;
   };
 
@@ -121,18 +129,20 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
     const long long rows = (long long)p->B * p->H * p->Nq;
     hipError_t e;
     if (p->dtype == TFA_BF16)
-      e = wide ? tfa::launch_delta<__bf16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
-               : tfa::launch_delta<__bf16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry);
+      e = wide256 ? tfa::launch_delta<__bf16, 256>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
+          : wide  ? tfa::launch_delta<__bf16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
+                  : tfa::launch_delta<__bf16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry);
     else
-      e = wide ? tfa::launch_delta<_Float16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
-               : tfa::launch_delta<_Float16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry);
+      e = wide256 ? tfa::launch_delta<_Float16, 256>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
+          : wide  ? tfa::launch_delta<_Float16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
+                  : tfa::launch_delta<_Float16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry);
     if (e != hipSuccess) return (int)e;
   }
   // ---- with a workspace: dK/dV launch that also writes dS, then dQ = scale * dS . K (5 GEMM units) -----------------------------
   int nk_pad = 0, nq_pad = 0;
   const long long need = ws_bytes(p, &nk_pad, &nq_pad);
   if (p->workspace && (((uintptr_t)p->workspace) & 15)) return TFA_ERR_ALIGN;
-  const bool use_ws = p->workspace != nullptr && need > 0 && p->workspace_bytes >= need && !g_bwd_split;
+  const bool use_ws = p->workspace != nullptr && need > 0 && p->workspace_bytes >= need && !g_bwd_split && !wide256;
   if (use_ws) {
     tfa::BArgs m = a;
     m.ws = p->workspace; m.ws_nk = nk_pad; m.ws_nq = nq_pad;
@@ -163,7 +173,7 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   }
   int st = launch(tfa::BWD_DQ, p->dq, p->dq_stride, p->Nq, p->H);
   if (st) return st;
-  if (g_bwd_split) {                                       // debug / A-B: the two single-gradient launches (S computed twice)
+  if (g_bwd_split || wide256) {                            // head dims above 128, and debug / A-B: the two single-gradient launches (S computed twice)
     st = launch(tfa::BWD_DK, p->dk, p->dk_stride, p->Nk, p->Hk);
     if (st) return st;
     return launch(tfa::BWD_DV, p->dv, p->dv_stride, p->Nk, p->Hk);

@@ -58,14 +58,17 @@ enum { BWD_DQ = 0, BWD_DK = 1, BWD_DV = 2 };
 // ds_read_b64_tr_b16 group addresses, the 64-byte spans (4 chunks) land in different aligned groups of 4 chunks
 // (D=128), resp. in the other half of the 256-byte bank row (D=64).
 template <int D> static __device__ __forceinline__ int u_swz(int row) {
-  return D == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+  // (D = 256: 32 chunks per 512-byte row; the XOR stays inside a 16-chunk half, and a row is two whole 256-byte bank rows, so the
+  //  bank of a chunk depends on (chunk ^ swizzle) alone: the D = 128 pattern serves)
+  return D >= 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
 }
 
-template <typename T, int D, int MODE, bool CAUSAL, bool F32OUT, bool UNI = false>
-__global__ __launch_bounds__(512, 2) void bwd_kernel(const BArgs p) {
+// NW = 8 (two waves per SIMD; head dims up to 128) or 4 (ONE wave per SIMD with the whole 512-entry register file: head dims up to 256 —
+// 128 resident-fragment + 128 accumulator registers in the dK launch —, unified images; hipcc places the accumulators in AGPRs)
+template <typename T, int D, int MODE, bool CAUSAL, bool F32OUT, bool UNI = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BArgs p) {
   using E = Elem<T>;
   using X8 = typename E::x8;
-  constexpr int NW = 8;
   constexpr int BM = NW * 32;                      // resident rows per workgroup
   constexpr int BN = 64;                           // streamed rows per tile
   constexpr int CPR = D / 8;

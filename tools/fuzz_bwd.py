@@ -1,5 +1,5 @@
 """Randomised cross-check of tfa_bwd against fp32 autograd on the device: random B, H, Hk, Nq, Nk, D (multiples of 8 up to
-128), dtype, causal, layout.  Bar per gradient: max|d| <= 2e-2 * max|ref| + 1e-3 (16-bit P, dS and outputs; the per-element
+256), dtype, causal, layout.  Bar per gradient: max|d| <= 2e-2 * max|ref| + 1e-3 (16-bit P, dS and outputs; the per-element
 bounds are tests/test_bwd_gpu.py's job).  usage: python tools/fuzz_bwd.py [--n 150] [--seed 0]"""
 import argparse, math, os, random, sys
 import torch
@@ -16,7 +16,7 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(a.seed)
 bad = 0
 for it in range(a.n):
-    D = rng.choice([64, 128, 128, 64, 32, 96, 72, 8, 120])
+    D = rng.choice([64, 128, 128, 64, 32, 96, 72, 8, 120, 160, 256, 200])
     dt = rng.choice([torch.bfloat16, torch.float16])
     causal = rng.random() < 0.6
     Hk = rng.choice([1, 2, 4])
