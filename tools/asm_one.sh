@@ -23,4 +23,4 @@ grep -E "VGPRs:|AGPRs|Spill|ScratchSize" res.txt | sed 's/remark: [^ ]* *//; s/\
 S=$(ls one-hip-amdgcn*.s | head -1)
 awk '/^_ZN3tfa13fwd_kernel_x4/,/s_endpgm/' $S > one.s
 echo "one.s: $(wc -l < one.s) lines, scratch ops $(grep -c scratch_ one.s), v_accvgpr $(grep -c v_accvgpr one.s), mfma $(grep -c v_mfma one.s)"
-python3 $ROOT/tools/x4_loop_stats.py /tmp/x4/one.s --min 40 | grep -v "VALU ops"
+python3 $ROOT/experiments/tools/x4_loop_stats.py /tmp/x4/one.s --min 40 | grep -v "VALU ops"
