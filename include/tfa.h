@@ -71,8 +71,8 @@ enum tfa_status {
   TFA_ERR_SHAPE = -4,         /* B,H,Hk,Nq,Nk <= 0 or H % Hk != 0 */
   TFA_ERR_STRIDE = -5,        /* a stride is negative, not 16-byte aligned, rows overlap, or 768 rows of a (b,h) slice span 2 GiB
                                * (tfa_fwd with D <= 128 switches to per-block / per-tile descriptor windows when a slice is larger,
-                               * ~6 % slower; D > 128, tfa_fwd_splitkv and tfa_bwd use one descriptor per slice: the whole slice
-                               * must stay below 2 GiB) */
+                               * ~6 % slower, and so does tfa_bwd for D <= 128; D > 128 and tfa_fwd_splitkv use one descriptor per
+                               * slice: the whole slice must stay below 2 GiB) */
   TFA_ERR_ALIGN = -6,         /* a base pointer is not 16-byte aligned */
   TFA_ERR_VARIANT = -7,       /* unknown kernel variant */
   TFA_ERR_SCALE = -8          /* softmax_scale is not finite or is <= 0 */
@@ -229,8 +229,8 @@ typedef struct tfa_bwd_params {
  * Head dims 136..256: three single-gradient launches (dQ, dK, dV) of the 256-wide kernel, one wave per SIMD.
  * Deterministic: no atomics, fixed summation order. */
 int tfa_bwd(const tfa_bwd_params* p, void* stream);
-/* Debug / A-B (per thread): on != 0 makes tfa_bwd run dK and dV as two single-gradient launches (S computed twice: the form of
- * versions <= 0.1.4). */
+/* Debug / A-B (per thread): bit 0 makes tfa_bwd run dK and dV as two single-gradient launches (S computed twice: the form of
+ * versions <= 0.1.4); bit 1 forces the windowed instantiations (the ones slices of 2 GiB and more get) on any problem. */
 int tfa_debug_bwd_split(int on);
 /* Validate *p without launching (no GPU needed). */
 int tfa_bwd_plan(const tfa_bwd_params* p);

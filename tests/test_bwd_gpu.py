@@ -197,3 +197,64 @@ def test_bwd_headline_shape_properties(tfa, dev):
     lhs = (dq.float() * q.float()).sum(dim=(2, 3))
     rhs = (dk.float() * k.float()).sum(dim=(2, 3))
     assert (lhs - rhs).abs().max().item() <= 2e-2 * max(1.0, lhs.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D,causal,layout", [
+    (torch.bfloat16, 2, 4, 2, 700, 900, 128, True, "bhnd"),
+    (torch.float16, 1, 4, 4, 513, 513, 64, True, "bnhd"),
+    (torch.bfloat16, 1, 6, 2, 320, 200, 96, False, "bnhd"),
+])
+def test_bwd_windowed_instantiations_return_the_same_bits(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, layout):
+    """The windowed instantiations of the dQ launch and of the fused dK/dV launch (what slices of 2 GiB and more get) forced onto
+    ordinary inputs through the debug knob: bit-identical gradients."""
+    from tiny_flash_attention_amd import _lib, ops
+
+    q, k, v = oracle.make_inputs(B, H, Nq, D, dtype, seed=61, Hk=Hk, Nk=Nk)
+    dout = make_dout(B, H, Nq, D, dtype, 62)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, dout))
+    if layout == "bnhd":
+        qd, kd, vd, dod = (t.transpose(1, 2).contiguous() for t in (qd, kd, vd, dod))
+    sc = 1.0 / math.sqrt(D)
+    out, lse = ops.flash_attn_fwd(qd, kd, vd, causal, sc, layout=layout)
+    g0 = ops.flash_attn_bwd(qd, kd, vd, out, lse, dod, causal, sc, layout=layout)
+    _lib.debug_bwd_split(2)
+    try:
+        g1 = ops.flash_attn_bwd(qd, kd, vd, out, lse, dod, causal, sc, layout=layout)
+        torch.cuda.synchronize()
+    finally:
+        _lib.debug_bwd_split(0)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+
+
+def test_bwd_head_slices_beyond_2_gib_in_bnhd_layout(tfa, dev):
+    """(B,N,H,D) storage with many heads: one (b,h) slice of q, k, v, dout and of every gradient spans 2.28e9 bytes — more than a
+    32-bit buffer offset reaches.  tfa_bwd then runs the windowed instantiations; three heads are checked against fp32 autograd
+    on the device (the rows near the END of the sequence are the ones whose offsets exceed 2 GiB)."""
+    from tiny_flash_attention_amd import ops
+
+    B, N, H, D = 1, 17408, 512, 128
+    assert (N - 1) * H * D * 2 > 2 ** 31
+    g = torch.Generator(device=dev).manual_seed(93)
+    mk = lambda: torch.empty((B, N, H, D), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(torch.bfloat16)
+    q, k, v, dout = mk(), mk(), mk(), mk()
+    sc = 1.0 / math.sqrt(D)
+    out, lse = ops.flash_attn_fwd(q, k, v, True, sc, layout="bnhd")
+    dq, dk, dv = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, sc, layout="bnhd")
+    torch.cuda.synchronize()
+    del out
+    idx = torch.arange(N, device=dev)
+    for h in (0, 257, 511):
+        qh, kh, vh = (t[0, :, h].float().detach().requires_grad_(True) for t in (q, k, v))
+        s_ = (qh @ kh.t()) * sc
+        s_ = s_.masked_fill(idx[None, :] > idx[:, None], float("-inf"))
+        o = torch.softmax(s_, dim=-1) @ vh
+        o.backward(dout[0, :, h].float())
+        for name, got, want in (("dq", dq[0, :, h], qh.grad), ("dk", dk[0, :, h], kh.grad), ("dv", dv[0, :, h], vh.grad)):
+            gt = got.float()
+            assert bool(torch.isfinite(gt).all()), name
+            d = (gt - want).abs()
+            bar = 2e-2 * want.abs().max().item() + 1e-3
+            assert d.max().item() <= bar, f"head {h} {name}: max|d| {d.max().item():.3e} > {bar:.3e}"
+            assert d[-640:].max().item() <= bar                              # the tail of the sequence: offsets beyond 2 GiB
+        del s_, o, qh, kh, vh

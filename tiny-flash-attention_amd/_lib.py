@@ -201,7 +201,7 @@ def debug_set_flags(flags):
 
 def debug_bwd_split(on):
     """tfa_debug_bwd_split: dK and dV as two launches (A/B and cross-check of the fused dK/dV kernel)."""
-    check(lib().tfa_debug_bwd_split(1 if on else 0))
+    check(lib().tfa_debug_bwd_split(int(on)))       # bit 0: two-launch dK/dV form; bit 1: force the windowed (>= 2 GiB) instantiations
 
 
 def get_variant():

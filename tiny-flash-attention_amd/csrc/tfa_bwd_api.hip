@@ -33,20 +33,30 @@ template <> hipError_t launch_delta<_Float16, 256>(const void*, const void*, flo
 
 namespace {
 
-thread_local int g_bwd_split = 0;   // tfa_debug_bwd_split(1): dK and dV as two launches (the round-1/2 form), for A/B and parity cross-checks
+thread_local int g_bwd_split = 0;   // tfa_debug_bwd_split: bit 0 = dK and dV as two launches (the round-1/2 form), bit 1 = force the windowed
+                                    // (>= 2 GiB slices) instantiations on any problem; for A/B and parity cross-checks
 
-bool slice_bytes(int64_t n, int64_t row_stride, int d, int esize, unsigned* out) {
+// extent of one (b,h) slice.  Kernels with one descriptor per slice need every byte offset they form (up to 512 rows past the end)
+// inside int32; the BIG instantiations (windowed descriptors, tfa_bwd_kernel.h) only need a window — 768 rows — to fit, and are
+// launched when *big comes back set.  big == nullptr: the caller has no windowed form.
+bool slice_bytes(int64_t n, int64_t row_stride, int d, int esize, unsigned* out, unsigned long long* full = nullptr, int* big = nullptr) {
   const int64_t bytes = ((n - 1) * row_stride + d) * esize;
   const int64_t reach = ((n + 512) * row_stride + d) * esize;   // every byte offset a kernel forms stays inside int32
-  if (bytes <= 0 || reach >= (int64_t)0x7fffffff) return false;
-  *out = (unsigned)bytes;
+  const int64_t window = (768 * row_stride + d) * esize;
+  if (bytes <= 0) return false;
+  if (reach >= (int64_t)0x7fffffff) {
+    if (!big || window >= (int64_t)0x7fffffff) return false;
+    *big = 1;
+  }
+  *out = (unsigned)(bytes < (int64_t)0x7fffffff ? bytes : (int64_t)0x7fffffff);
+  if (full) *full = (unsigned long long)bytes;
   return true;
 }
 
-bool fill(tfa::BTensor* t, const void* ptr, const int64_t* st, int64_t n, int d, int esize) {
+bool fill(tfa::BTensor* t, const void* ptr, const int64_t* st, int64_t n, int d, int esize, int* big) {
   t->p = ptr;
   t->s_b = st[0]; t->s_h = st[1]; t->s_n = st[2];
-  return slice_bytes(n, st[2], d, esize, &t->bytes);
+  return slice_bytes(n, st[2], d, esize, &t->bytes, &t->full, big);
 }
 
 int check_strides(const int64_t* st, int d, int esize) {
@@ -88,12 +98,23 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
 
   tfa::BArgs a;
   memset(&a, 0, sizeof(a));
-  if (!fill(&a.q, p->q, p->q_stride, p->Nq, p->D, esz)) return TFA_ERR_STRIDE;
-  if (!fill(&a.k, p->k, p->k_stride, p->Nk, p->D, esz)) return TFA_ERR_STRIDE;
-  if (!fill(&a.v, p->v, p->v_stride, p->Nk, p->D, esz)) return TFA_ERR_STRIDE;
-  if (!fill(&a.dout, p->dout, p->do_stride, p->Nq, p->D, esz)) return TFA_ERR_STRIDE;
-  unsigned ob = 0;
-  if (!slice_bytes(p->Nq, p->o_stride[2], p->D, esz, &ob)) return TFA_ERR_STRIDE;
+  // slices of 2 GiB and more (long (B,N,H,D) tensors): the windowed instantiations of the dQ launch and of the fused dK/dV launch —
+  // head dims up to 128, not with the two-launch debug form
+  const bool can_big = p->D <= 128 && !(g_bwd_split & 1);
+  int big = (g_bwd_split & 2) ? 1 : 0;        // tests: the windowed instantiations on a small problem
+  int* bigp = can_big ? &big : nullptr;
+  if (!fill(&a.q, p->q, p->q_stride, p->Nq, p->D, esz, bigp)) return TFA_ERR_STRIDE;
+  if (!fill(&a.k, p->k, p->k_stride, p->Nk, p->D, esz, bigp)) return TFA_ERR_STRIDE;
+  if (!fill(&a.v, p->v, p->v_stride, p->Nk, p->D, esz, bigp)) return TFA_ERR_STRIDE;
+  if (!fill(&a.dout, p->dout, p->do_stride, p->Nq, p->D, esz, bigp)) return TFA_ERR_STRIDE;
+  {   // out (read by the delta kernel through plain 64-bit pointers) and the gradients: same rule
+    unsigned tmp; unsigned long long tmpf;
+    if (!slice_bytes(p->Nq, p->o_stride[2], p->D, esz, &tmp, &tmpf, bigp) || !slice_bytes(p->Nq, p->dq_stride[2], p->D, gsz, &tmp, &tmpf, bigp) ||
+        !slice_bytes(p->Nk, p->dk_stride[2], p->D, gsz, &tmp, &tmpf, bigp) || !slice_bytes(p->Nk, p->dv_stride[2], p->D, gsz, &tmp, &tmpf, bigp))
+      return TFA_ERR_STRIDE;
+  }
+  if (big && !can_big) return TFA_ERR_STRIDE;
+  a.big = big;
   a.lse = p->lse; a.delta = p->delta;
   a.B = p->B; a.H = p->H; a.Hk = p->Hk; a.Nq = p->Nq; a.Nk = p->Nk;
   a.dv = p->D;
@@ -107,7 +128,7 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   auto launch = [&](int mode, void* grad, const int64_t* gst, int n_res, int h_res) -> int {
     tfa::BArgs m = a;
     m.grad = grad; m.gs_b = gst[0]; m.gs_h = gst[1]; m.gs_n = gst[2];
-    if (!slice_bytes(n_res, gst[2], p->D, gsz, &m.g_bytes)) return TFA_ERR_STRIDE;
+    if (!slice_bytes(n_res, gst[2], p->D, gsz, &m.g_bytes, &m.g_full, bigp)) return TFA_ERR_STRIDE;
     const int res_rows = wide256 ? 128 : 256;
     m.nrb = (n_res + res_rows - 1) / res_rows;
     const int64_t grid = (int64_t)p->B * h_res * m.nrb;
@@ -142,7 +163,7 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   int nk_pad = 0, nq_pad = 0;
   const long long need = ws_bytes(p, &nk_pad, &nq_pad);
   if (p->workspace && (((uintptr_t)p->workspace) & 15)) return TFA_ERR_ALIGN;
-  const bool use_ws = p->workspace != nullptr && need > 0 && p->workspace_bytes >= need && !g_bwd_split && !wide256;
+  const bool use_ws = p->workspace != nullptr && need > 0 && p->workspace_bytes >= need && !(g_bwd_split & 1) && !wide256 && !big;
   if (use_ws) {
     tfa::BArgs m = a;
     m.ws = p->workspace; m.ws_nk = nk_pad; m.ws_nq = nq_pad;
@@ -173,7 +194,7 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   }
   int st = launch(tfa::BWD_DQ, p->dq, p->dq_stride, p->Nq, p->H);
   if (st) return st;
-  if (g_bwd_split || wide256) {                            // head dims above 128, and debug / A-B: the two single-gradient launches (S computed twice)
+  if ((g_bwd_split & 1) || wide256) {                            // head dims above 128, and debug / A-B: the two single-gradient launches (S computed twice)
     st = launch(tfa::BWD_DK, p->dk, p->dk_stride, p->Nk, p->Hk);
     if (st) return st;
     return launch(tfa::BWD_DV, p->dv, p->dv_stride, p->Nk, p->Hk);
@@ -182,7 +203,8 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   tfa::BArgs m = a;
   m.grad = p->dk; m.gs_b = p->dk_stride[0]; m.gs_h = p->dk_stride[1]; m.gs_n = p->dk_stride[2];
   m.grad2 = p->dv; m.g2s_b = p->dv_stride[0]; m.g2s_h = p->dv_stride[1]; m.g2s_n = p->dv_stride[2];
-  if (!slice_bytes(p->Nk, p->dk_stride[2], p->D, gsz, &m.g_bytes) || !slice_bytes(p->Nk, p->dv_stride[2], p->D, gsz, &m.g2_bytes)) return TFA_ERR_STRIDE;
+  if (!slice_bytes(p->Nk, p->dk_stride[2], p->D, gsz, &m.g_bytes, &m.g_full, bigp) ||
+      !slice_bytes(p->Nk, p->dv_stride[2], p->D, gsz, &m.g2_bytes, &m.g2_full, bigp)) return TFA_ERR_STRIDE;
   constexpr int kv_keys = 32 * TFA_BWD_KV_KG_OF(false);   // resident keys per workgroup of the fused launch
   m.nrb = (p->Nk + kv_keys - 1) / kv_keys;
   const int64_t grid = (int64_t)p->B * p->Hk * m.nrb;
@@ -201,7 +223,7 @@ extern "C" {
 
 int tfa_bwd(const tfa_bwd_params* p, void* stream) { return run_bwd(p, stream, false); }
 int tfa_bwd_plan(const tfa_bwd_params* p) { return run_bwd(p, nullptr, true); }
-int tfa_debug_bwd_split(int on) { g_bwd_split = on ? 1 : 0; return TFA_OK; }
+int tfa_debug_bwd_split(int on) { g_bwd_split = on & 3; return TFA_OK; }
 long long tfa_bwd_workspace_bytes(const tfa_bwd_params* p) {
   tfa_bwd_params q;
   if (!p) return TFA_ERR_NULL;

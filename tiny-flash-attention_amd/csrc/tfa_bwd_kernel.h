@@ -27,7 +27,8 @@ namespace tfa {
 struct BTensor {
   const void* p;
   long long s_b, s_h, s_n;   // strides in elements; unit stride along D
-  unsigned bytes;            // extent of one (b,h) slice in bytes (buffer descriptor range)
+  unsigned bytes;            // extent of one (b,h) slice in bytes (buffer descriptor range; clamped to 2 GiB - 1 when the slice is larger)
+  unsigned long long full;   // the slice's true extent: the BIG instantiations address it through windows (rsrc_at)
 };
 
 struct BArgs {
@@ -45,6 +46,8 @@ struct BArgs {
   void* grad2;               // bwd_kv_kernel (tfa_bwd_kv_kernel.h): `grad` = dK, `grad2` = dV
   long long g2s_b, g2s_h, g2s_n;
   unsigned g2_bytes;
+  unsigned long long g_full, g2_full;   // true extents of the gradient slices (BIG)
+  int big;                   // some slice reaches 2 GiB: the host launches the BIG instantiations
   void* ws;                  // optional dS workspace (tfa_bwd_params::workspace): dS^T[b][query head][ws_nk key rows][ws_nq queries], 16 bit
   int ws_nk, ws_nq;          // padded extents: Nk rounded up to 128, Nq rounded up to 256
 };
@@ -65,8 +68,13 @@ template <int D> static __device__ __forceinline__ int u_swz(int row) {
 
 // NW = 8 (two waves per SIMD; head dims up to 128) or 4 (ONE wave per SIMD with the whole 512-entry register file: head dims up to 256 —
 // 128 resident-fragment + 128 accumulator registers in the dK launch —, unified images; hipcc places the accumulators in AGPRs)
-template <typename T, int D, int MODE, bool CAUSAL, bool F32OUT, bool UNI = false, int NW = 8>
+// BIG: (b,h) slices of 2 GiB and more (long (B,N,H,D) tensors): every descriptor is a WINDOW (rsrc_at) — one per streamed tile, one
+// over the workgroup's resident rows, one over its gradient rows — and the 32-bit offsets are window-relative.  Its own instantiation
+// (a fresh descriptor per tile costs scalar work and wait states), launched only when a slice needs it; dQ mode only (the fused
+// dK/dV launch has its own).
+template <typename T, int D, int MODE, bool CAUSAL, bool F32OUT, bool UNI = false, int NW = 8, bool BIG = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BArgs p) {
+  static_assert(!BIG || MODE == BWD_DQ, "BIG: the dQ launch");
   using E = Elem<T>;
   using X8 = typename E::x8;
   constexpr int BM = NW * 32;                      // resident rows per workgroup
@@ -191,6 +199,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
     for (int img = 0; img < NIMG; ++img) {
       const BTensor& x = img_tensor(img);
       const T* base = reinterpret_cast<const T*>(x.p) + b * x.s_b + hs * x.s_h;
+      if constexpr (BIG) {
+        const auto rsw = rsrc_at(base, x.full, (unsigned long long)jt * (unsigned)tile_stride[img]);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+          lds_dma16_m0_fresh(rsw, lds_base + (stage * NIMG + img) * TILE_BYTES + (wave * PPW + i) * 1024, src[img][i]);
+        continue;
+      }
       auto rs = KEYS_RES ? __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000) : rs_fixed[img];
 #pragma unroll
       for (int i = 0; i < PPW; ++i)
@@ -203,15 +218,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
   {
     const BTensor& x1 = KEYS_RES ? p.k : p.q;
     const T* b1 = reinterpret_cast<const T*>(x1.p) + b * x1.s_b + hr * x1.s_h;
-    auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, x1.bytes, 0x00020000);
-    const int off1 = my_row * (int)x1.s_n * 2 + hi * 16;
+    auto rs1 = BIG ? rsrc_at(b1, x1.full, (unsigned long long)r0 * (unsigned long long)x1.s_n * 2ull) : __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, x1.bytes, 0x00020000);
+    const int off1 = (my_row - (BIG ? r0 : 0)) * (int)x1.s_n * 2 + hi * 16;
 #pragma unroll
     for (int s = 0; s < DS; ++s) r1f[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs1, (2 * s + hi) * 8 < p.dv ? off1 + s * 32 : (int)TFA_OOB, 0, 0));
     if (NEED_DP) {
       const BTensor& x2 = KEYS_RES ? p.v : p.dout;
       const T* b2 = reinterpret_cast<const T*>(x2.p) + b * x2.s_b + hr * x2.s_h;
-      auto rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)b2, 0, x2.bytes, 0x00020000);
-      const int off2 = my_row * (int)x2.s_n * 2 + hi * 16;
+      auto rs2 = BIG ? rsrc_at(b2, x2.full, (unsigned long long)r0 * (unsigned long long)x2.s_n * 2ull) : __builtin_amdgcn_make_buffer_rsrc((void*)b2, 0, x2.bytes, 0x00020000);
+      const int off2 = (my_row - (BIG ? r0 : 0)) * (int)x2.s_n * 2 + hi * 16;
 #pragma unroll
       for (int s = 0; s < DS; ++s) r2f[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs2, (2 * s + hi) * 8 < p.dv ? off2 + s * 32 : (int)TFA_OOB, 0, 0));
     }
@@ -370,8 +385,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
   const float osc = (MODE == BWD_DV) ? 1.f : p.scale;
   if (F32OUT) {
     float* gb = reinterpret_cast<float*>(p.grad) + b * p.gs_b + hr * p.gs_h;
-    auto g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, p.g_bytes, 0x00020000);
-    const int goff = my_row * (int)p.gs_n * 4 + hi * 16;
+    auto g_rs = BIG ? rsrc_at(gb, p.g_full, (unsigned long long)r0 * (unsigned long long)p.gs_n * 4ull) : __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, p.g_bytes, 0x00020000);
+    const int goff = (my_row - (BIG ? r0 : 0)) * (int)p.gs_n * 4 + hi * 16;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -381,8 +396,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
       }
   } else {
     T* gb = reinterpret_cast<T*>(p.grad) + b * p.gs_b + hr * p.gs_h;
-    auto g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, p.g_bytes, 0x00020000);
-    const int goff = my_row * (int)p.gs_n * 2 + hi * 8;
+    auto g_rs = BIG ? rsrc_at(gb, p.g_full, (unsigned long long)r0 * (unsigned long long)p.gs_n * 2ull) : __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, p.g_bytes, 0x00020000);
+    const int goff = (my_row - (BIG ? r0 : 0)) * (int)p.gs_n * 2 + hi * 8;
     typedef __attribute__((ext_vector_type(4))) T t4;
 #pragma unroll
     for (int d = 0; d < DT; ++d)

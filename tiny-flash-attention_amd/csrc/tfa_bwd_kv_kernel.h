@@ -26,8 +26,11 @@ namespace tfa {
 // GEMM instead of recomputing S and dP.  Every (128-key block, 64-query tile) pair this kernel visits is written completely
 // (fully masked 32-key pieces as zeros); pairs it does not visit are entirely above the causal diagonal and the consumer
 // never reads them.
-template <typename T, int D, bool CAUSAL, bool F32OUT, bool WS = false, int KG = 4>
+// BIG: (b,h) slices of 2 GiB and more — windowed descriptors as in bwd_kernel (one per streamed tile and image, one over the
+// workgroup's resident rows, one over its gradient rows); its own instantiation, without the workspace form.
+template <typename T, int D, bool CAUSAL, bool F32OUT, bool WS = false, int KG = 4, bool BIG = false>
 __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const BArgs p) {
+  static_assert(!(BIG && WS), "the workspace form keeps one descriptor per slice");
   using E = Elem<T>;
   using X8 = typename E::x8;
   constexpr int NW = 2 * KG;                       // KG key groups x 2 roles (KG = 6: three waves per SIMD, 168 registers each)
@@ -113,9 +116,20 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000);
   };
   auto q_rs = head_rsrc(p.q, 0), do_rs = head_rsrc(p.dout, 0);
+  auto head_base = [&](const BTensor& x, int g) { return reinterpret_cast<const T*>(x.p) + b * x.s_b + (hr * G + g) * x.s_h; };
   int jt_d = t_begin, g_d = 0;                     // position of the NEXT tile to request
   auto dma_next = [&](int stage) {
     if (KG != 4 && wave >= NDMA) return;             // (KG = 6: the tile's pieces are issued by the first eight waves)
+    if constexpr (BIG) {
+      const auto qw = rsrc_at(head_base(p.q, g_d), p.q.full, (unsigned long long)jt_d * (unsigned)tile_stride[0]);
+      const auto dw = rsrc_at(head_base(p.dout, g_d), p.dout.full, (unsigned long long)jt_d * (unsigned)tile_stride[1]);
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) lds_dma16_m0_fresh(qw, lds_base + stage * STAGE_BYTES + (wave * PPW + i) * 1024, src[0][i]);
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) lds_dma16_m0_fresh(dw, lds_base + stage * STAGE_BYTES + TILE_BYTES + (wave * PPW + i) * 1024, src[1][i]);
+      if (++jt_d == t_end) { jt_d = t_begin; ++g_d; }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
       lds_dma16_m0(q_rs, lds_base + stage * STAGE_BYTES + (wave * PPW + i) * 1024, src[0][i] + jt_d * tile_stride[0]);
@@ -133,8 +147,8 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   {
     const BTensor& x = role ? p.v : p.k;
     const T* b1 = reinterpret_cast<const T*>(x.p) + b * x.s_b + hr * x.s_h;
-    auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, x.bytes, 0x00020000);
-    const int off1 = my_row * (int)x.s_n * 2 + hi * 16;
+    auto rs1 = BIG ? rsrc_at(b1, x.full, (unsigned long long)r0 * (unsigned long long)x.s_n * 2ull) : __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, x.bytes, 0x00020000);
+    const int off1 = (my_row - (BIG ? r0 : 0)) * (int)x.s_n * 2 + hi * 16;
 #pragma unroll
     for (int s = 0; s < DS; ++s) rf[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs1, (2 * s + hi) * 8 < p.dv ? off1 + s * 32 : (int)TFA_OOB, 0, 0));
   }
@@ -317,10 +331,11 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   const long long gsb = role ? p.gs_b : p.g2s_b, gsh = role ? p.gs_h : p.g2s_h;
   const int gsn = (int)(role ? p.gs_n : p.g2s_n);
   const unsigned gbytes = role ? p.g_bytes : p.g2_bytes;
+  const unsigned long long gfull = role ? p.g_full : p.g2_full;
   if (F32OUT) {
     float* gb = reinterpret_cast<float*>(gp) + b * gsb + hr * gsh;
-    auto g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, gbytes, 0x00020000);
-    const int goff = my_row * gsn * 4 + hi * 16;
+    auto g_rs = BIG ? rsrc_at(gb, gfull, (unsigned long long)r0 * (unsigned long long)gsn * 4ull) : __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, gbytes, 0x00020000);
+    const int goff = (my_row - (BIG ? r0 : 0)) * gsn * 4 + hi * 16;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -330,8 +345,8 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
       }
   } else {
     T* gb = reinterpret_cast<T*>(gp) + b * gsb + hr * gsh;
-    auto g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, gbytes, 0x00020000);
-    const int goff = my_row * gsn * 2 + hi * 8;
+    auto g_rs = BIG ? rsrc_at(gb, gfull, (unsigned long long)r0 * (unsigned long long)gsn * 2ull) : __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, gbytes, 0x00020000);
+    const int goff = (my_row - (BIG ? r0 : 0)) * gsn * 2 + hi * 8;
     typedef __attribute__((ext_vector_type(4))) T t4;
 #pragma unroll
     for (int d = 0; d < DT; ++d)

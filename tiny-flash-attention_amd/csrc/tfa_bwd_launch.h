@@ -6,10 +6,13 @@
 #include "tfa_bwd_dq_kernel.h"
 #include "tfa_host_util.h"
 
-// key groups (32 resident keys each) per workgroup of the fused dK/dV kernel: 4 (eight waves, two per SIMD) or 6 (twelve waves,
-// three per SIMD, 168 registers each); the workspace form is blocked by 128 keys and stays at 4
+// key groups (32 resident keys each) per workgroup of the fused dK/dV kernel: 4 (eight waves, two per SIMD, 186 registers, no
+// scratch — the default) or 6 (twelve waves, three per SIMD at 168 registers with 15-18 of them spilled: 1-3 % faster in one
+// measurement, 15 % SLOWER in the next build of the same kernel code once other scratch-using kernels shared the library —
+// profiles/r03_bwd_kg_ab.txt; a kernel that touches scratch is at the mercy of the runtime's scratch sizing, so it stays an arm:
+// -DTFA_BWD_KV_KG=6).  The workspace form is blocked by 128 keys and always uses 4.
 #ifndef TFA_BWD_KV_KG
-#define TFA_BWD_KV_KG 6
+#define TFA_BWD_KV_KG 4
 #endif
 #define TFA_BWD_KV_KG_OF(WS) ((WS) ? 4 : TFA_BWD_KV_KG)
 
