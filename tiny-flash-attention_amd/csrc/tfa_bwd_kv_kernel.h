@@ -52,6 +52,8 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   char* const pbuf = smem + NSTAGE * STAGE_BYTES;  // [2 parities][KG][PX_BYTES]
+  constexpr int ST_OFF = NSTAGE * STAGE_BYTES + 2 * KG * PX_BYTES;   // per stage: LSE of the tile's 64 query rows (256 B), delta (256 B)
+  const char* const sbuf = smem + ST_OFF;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -115,11 +117,20 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
     const T* base = reinterpret_cast<const T*>(x.p) + b * x.s_b + (hr * G + g) * x.s_h;
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000);
   };
+  // per tile-row statistics (LSE for role 0, delta for role 1) travel WITH the tile, by LDS-DMA (one dword per lane = the tile's 64
+  // rows; waves 0 and 1 issue them): loaded from global memory by every lane they sat in the same in-order vmcnt queue as the next
+  // tile's DMA pieces, so the first use of a statistic waited for that whole tile to land.  Out-of-range rows read as 0.
+  auto stat_rsrc = [&](const float* base, int g) {
+    const long long so = (long long)(b * p.H + hr * G + g) * p.Nq;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + so), 0, (unsigned)p.Nq * 4u, 0x00020000);
+  };
+  auto lse_rs = stat_rsrc(p.lse, 0), dl_rs = stat_rsrc(p.delta, 0);
   auto q_rs = head_rsrc(p.q, 0), do_rs = head_rsrc(p.dout, 0);
   auto head_base = [&](const BTensor& x, int g) { return reinterpret_cast<const T*>(x.p) + b * x.s_b + (hr * G + g) * x.s_h; };
   int jt_d = t_begin, g_d = 0;                     // position of the NEXT tile to request
   auto dma_next = [&](int stage) {
     if (KG != 4 && wave >= NDMA) return;             // (KG = 6: the tile's pieces are issued by the first eight waves)
+    if (wave < 2) lds_dma4_m0(wave ? dl_rs : lse_rs, lds_base + ST_OFF + stage * 512 + wave * 256, (jt_d * BN + lane) * 4);
     if constexpr (BIG) {
       const auto qw = rsrc_at(head_base(p.q, g_d), p.q.full, (unsigned long long)jt_d * (unsigned)tile_stride[0]);
       const auto dw = rsrc_at(head_base(p.dout, g_d), p.dout.full, (unsigned long long)jt_d * (unsigned)tile_stride[1]);
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
       for (int i = 0; i < PPW; ++i) lds_dma16_m0_fresh(qw, lds_base + stage * STAGE_BYTES + (wave * PPW + i) * 1024, src[0][i]);
 #pragma unroll
       for (int i = 0; i < PPW; ++i) lds_dma16_m0_fresh(dw, lds_base + stage * STAGE_BYTES + TILE_BYTES + (wave * PPW + i) * 1024, src[1][i]);
-      if (++jt_d == t_end) { jt_d = t_begin; ++g_d; }
+      if (++jt_d == t_end) { jt_d = t_begin; if (++g_d < G) { lse_rs = stat_rsrc(p.lse, g_d); dl_rs = stat_rsrc(p.delta, g_d); } }
       return;
     }
 #pragma unroll
@@ -138,7 +149,7 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
       lds_dma16_m0(do_rs, lds_base + stage * STAGE_BYTES + TILE_BYTES + (wave * PPW + i) * 1024, src[1][i] + jt_d * tile_stride[1]);
     if (++jt_d == t_end) {
       jt_d = t_begin;
-      if (++g_d < G) { q_rs = head_rsrc(p.q, g_d); do_rs = head_rsrc(p.dout, g_d); }
+      if (++g_d < G) { q_rs = head_rsrc(p.q, g_d); do_rs = head_rsrc(p.dout, g_d); lse_rs = stat_rsrc(p.lse, g_d); dl_rs = stat_rsrc(p.delta, g_d); }
     }
   };
 
@@ -202,14 +213,8 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   asm volatile("s_barrier" ::: "memory");
 
   int jt_c = t_begin, g_c = 0;                       // this wave's tile: position inside the head, head
-  // per tile-row statistics: LSE (role 0) or delta (role 1) of the (b, query head) row; out of range -> 0
-  auto stat_rsrc = [&](int g) {
-    const long long so = (long long)(b * p.H + hr * G + g) * p.Nq;
-    return __builtin_amdgcn_make_buffer_rsrc((void*)((role ? p.delta : p.lse) + so), 0, (unsigned)p.Nq * 4u, 0x00020000);
-  };
-  auto st_rs = stat_rsrc(0);
   auto next_tile = [&]() {
-    if (++jt_c == t_end) { jt_c = t_begin; if (++g_c < G) st_rs = stat_rsrc(g_c); }
+    if (++jt_c == t_end) { jt_c = t_begin; ++g_c; }
   };
   int st_next = 1;                                   // stage of tile it+1
   int st_mine = role ? NSTAGE - 1 : 0;               // stage of this wave's tile (role 1: tile it-1)
@@ -243,24 +248,22 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
       }
       if (active) {
         // statistics of the 64 tile rows first (both halves): no load is issued between the dS stores below and the barrier
-        // (WS: both halves up front — no load may be issued between the dS stores and the barrier; otherwise per half: 16 live
-        //  registers fewer, which the three-waves-per-SIMD form needs)
+        // statistics of the tile's rows from the stage's LDS copy: this lane's 16 rows of half t are 4 runs of 4 consecutive rows
         float stv[2][16];
+        const char* const st_img = sbuf + st_mine * 512 + role * 256;
         auto load_stats = [&](int t) {
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
-            const int q = row0 + 32 * t + 8 * g4 + 4 * hi;
-            const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(st_rs, q * 4, 0, 0));
+            const f32x4 a = *reinterpret_cast<const f32x4*>(st_img + (32 * t + 8 * g4 + 4 * hi) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) stv[t][4 * g4 + e] = a[e];
           }
         };
-        if (WS) { load_stats(0); load_stats(1); }
         X8 keep[2][2];                                  // WS: dS of both halves, stored behind the tile's last MFMA
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           // ---- GEMM-I over the 32 tile rows of half t: S (role 0) or dP (role 1) -----------------------------------
-          if (!WS) load_stats(t);
+          load_stats(t);
           f32x16 x;
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[r] = 0.f;

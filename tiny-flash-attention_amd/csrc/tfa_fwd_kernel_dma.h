@@ -49,6 +49,17 @@ static __device__ __forceinline__ void lds_dma16_m0(__amdgpu_buffer_rsrc_t rs, u
       : "memory", "m0");
 }
 
+// The 4-byte form: one dword per lane, 256 contiguous bytes of LDS per wave-instruction (the backward's per-tile row statistics)
+static __device__ __forceinline__ void lds_dma4_m0(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, int voffset) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dword %1, %2, 0 offen lds"
+      :
+      : "s"(lds_addr), "v"(voffset), "s"(rs)
+      : "memory", "m0");
+}
+
 // The same with the non-temporal hint: K/V bytes nobody else will ask for (decode: one workgroup per K/V head)
 static __device__ __forceinline__ void lds_dma16_m0_nt(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, int voffset) {
   asm volatile(
