@@ -211,6 +211,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
       for (int i = 0; i < PPW; ++i)
         lds_dma16_m0(rs, lds_base + (stage * NIMG + img) * TILE_BYTES + (wave * PPW + i) * 1024, src[img][i] + jt * tile_stride[img]);
     }
+    if (KEYS_RES && wave < 2) {
+      // the tile's row statistics (LSE, delta: 64 rows = one dword per lane) travel with it — loaded from global memory by every lane
+      // they queue behind the next tile's DMA pieces in the in-order vmcnt (tfa_bwd_kv_kernel.h)
+      const long long so = (long long)(b * p.H + hs) * p.Nq;
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)((wave ? p.delta : p.lse) + so), 0, (unsigned)p.Nq * 4u, 0x00020000);
+      lds_dma4_m0(rs, lds_base + 2 * NIMG * TILE_BYTES + stage * 512 + wave * 256, (jt * BN + lane) * 4);
+    }
   };
 
   // ---- resident fragments and per-lane statistics -----------------------------------------------------------------
@@ -291,13 +298,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
       need_mask = CAUSAL && (row0 < wave_row0 + 31 - shift);
       if (CAUSAL) active = row0 + BN - 1 >= wave_row0 - shift;
     }
-    // per tile-row statistics (dK/dV): descriptor over the (b, h) row of the (B,H,Nq) arrays, OOB -> 0
-    __amdgpu_buffer_rsrc_t lse_rs, dl_rs;
-    if (KEYS_RES) {
-      const long long so = (long long)(b * p.H + hr * G + g) * p.Nq;
-      lse_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + so), 0, (unsigned)p.Nq * 4u, 0x00020000);
-      dl_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.delta + so), 0, (unsigned)p.Nq * 4u, 0x00020000);
-    }
+    const char* const st_img = smem + 2 * NIMG * TILE_BYTES + stage * 512;   // this tile's LSE (256 B) and delta (256 B)
 
     X8 pk[4];
     if (active) {
@@ -319,11 +320,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int q = row0 + 32 * t + 8 * g4 + 4 * hi;
-          const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lse_rs, q * 4, 0, 0));
+          const f32x4 a = *reinterpret_cast<const f32x4*>(st_img + (q - row0) * 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) lse2[4 * g4 + e] = a[e] * 1.4426950408889634f;
           if (NEED_DP) {
-            const f32x4 c = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dl_rs, q * 4, 0, 0));
+            const f32x4 c = *reinterpret_cast<const f32x4*>(st_img + 256 + (q - row0) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) dl[4 * g4 + e] = c[e];
           }
