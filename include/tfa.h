@@ -71,8 +71,8 @@ enum tfa_status {
   TFA_ERR_SHAPE = -4,         /* B,H,Hk,Nq,Nk <= 0 or H % Hk != 0 */
   TFA_ERR_STRIDE = -5,        /* a stride is negative, not 16-byte aligned, rows overlap, or 768 rows of a (b,h) slice span 2 GiB
                                * (tfa_fwd with D <= 128 switches to per-block / per-tile descriptor windows when a slice is larger,
-                               * ~6 % slower, and so does tfa_bwd for D <= 128; D > 128 and tfa_fwd_splitkv use one descriptor per
-                               * slice: the whole slice must stay below 2 GiB) */
+                               * ~6 % slower, and so does tfa_bwd for D <= 128; tfa_fwd_splitkv then runs one windowed launch per key
+                               * chunk; D > 128 uses one descriptor per slice: the whole slice must stay below 2 GiB) */
   TFA_ERR_ALIGN = -6,         /* a base pointer is not 16-byte aligned */
   TFA_ERR_VARIANT = -7,       /* unknown kernel variant */
   TFA_ERR_SCALE = -8          /* softmax_scale is not finite or is <= 0 */
@@ -264,7 +264,8 @@ int tfa_variant_available(int variant);
 int tfa_debug_set_trace(void* dev_buf);
 /* Kernel bring-up flags of the calling thread (0 = normal).  128: the trace stamps describe a causal workgroup's SECOND
  * pass (the light block) instead of the first; 256: launch the windowed-descriptor instantiation (the one slices of
- * 2 GiB and more get) whatever the slice size — tests compare its bits with the default; the low bits insert fences / force the burst path in the x4 kernel
+ * 2 GiB and more get) whatever the slice size — tests compare its bits with the default; 8192: tfa_fwd_splitkv takes its one-launch-per-chunk
+ * route (the one slices of 2 GiB and more and head dims above 128 take) on any problem; the low bits insert fences / force the burst path in the x4 kernel
  * (tfa_fwd_kernel_x4.h) and are only meaningful to tools/. */
 int tfa_debug_set_flags(int flags);
 

@@ -620,8 +620,8 @@ def test_head_slices_beyond_2_gib_in_bnhd_layout(tfa, dev):
     """(B,N,H,D) storage with many heads: one (b,h) slice spans N * H*D*2 bytes — here 2.2 GiB, more than a 32-bit buffer
     offset reaches.  The default il kernel then runs in its windowed instantiation (per-query-block and per-tile
     descriptors, rsrc_at in tfa_fwd_kernel.h); checked on sampled heads against a device fp32 reference (the rows near the
-    END of the sequence are the ones whose offsets exceed 2 GiB).  The single-descriptor kernels (split-KV, backward, head
-    dims > 128) still refuse."""
+    END of the sequence are the ones whose offsets exceed 2 GiB).  tfa_fwd_splitkv takes its one-launch-per-chunk route through the
+    same windowed kernels; head dims > 128 still need slices below 2 GiB."""
     from tiny_flash_attention_amd import _lib, ops
 
     B, N, H, D = 1, 17408, 512, 128                       # row stride H*D*2 = 128 KiB -> slice = 2.28e9 bytes
@@ -645,8 +645,13 @@ def test_head_slices_beyond_2_gib_in_bnhd_layout(tfa, dev):
         s0 = (qh[:256] @ kh[:256].t()) * sc                              # and the head of the sequence
         s0.masked_fill_(idx[None, :256] > idx[:256, None], float("-inf"))
         assert (out[0, :256, h].float() - torch.softmax(s0, dim=-1) @ vh[:256]).abs().max().item() <= 1e-2
-    with pytest.raises(_lib.TfaError):                                    # split-KV runs the single-descriptor kernel
-        ops.flash_attn_fwd_splitkv(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), True, sc, splits=2)
+    # split-KV on such slices: one launch of the windowed kernel per key chunk (the one-launch LDS-DMA kernel has one descriptor
+    # per slice), fp32 partials, same merge
+    o2, l2 = ops.flash_attn_fwd_splitkv(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), True, sc, splits=2)
+    torch.cuda.synchronize()
+    for h in (0, 257, 511):
+        assert (o2[0, h].float() - out[0, :, h].float()).abs().max().item() <= 4e-3
+        assert (l2[0, h] - lse[0, h]).abs().max().item() <= 1e-4
 
 
 @pytest.mark.parametrize("variant", [30, 32])

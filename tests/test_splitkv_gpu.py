@@ -23,7 +23,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("variant", [-1, 17, 27, 30, "native"])      # "native": tfa_fwd_splitkv, all chunks in one launch
+@pytest.mark.parametrize("variant", [-1, 17, 27, 30, "native", "native-chunks"])      # "native": tfa_fwd_splitkv, all chunks in one launch; "native-chunks": its one-launch-per-chunk route (what slices >= 2 GiB and head dims > 128 take), forced
 @pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D,causal,splits", [
     (torch.bfloat16, 1, 4, 4, 512, 512, 128, True, 2),
     (torch.bfloat16, 2, 4, 2, 300, 1000, 128, True, 3),      # GQA, ragged, Nq < Nk
@@ -42,7 +42,8 @@ def test_splitkv_matches_one_pass(oracle, dev, variant, dtype, B, H, Hk, Nq, Nk,
     q, k, v = oracle.make_inputs(B, H, Nq, D, dtype, seed=31, Hk=Hk, Nk=Nk)
     sc = 1.0 / math.sqrt(D)
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
-    native = variant == "native"
+    chunks = variant == "native-chunks"
+    native = variant == "native" or chunks
     if D > 128 and not (native or variant == -1):
         pytest.skip("head dims above 128 have one kernel: forced variants do not apply")
     if not native and variant >= 0 and not _lib.variant_available(variant):
@@ -50,9 +51,12 @@ def test_splitkv_matches_one_pass(oracle, dev, variant, dtype, B, H, Hk, Nq, Nk,
     _lib.set_variant(-1 if native else variant)
     try:
         full, lse_full = ops.flash_attn_fwd(qd, kd, vd, causal, sc)
+        if chunks:
+            _lib.debug_set_flags(8192)
         out, lse = ops.flash_attn_fwd_splitkv(qd, kd, vd, causal, sc, splits=splits, native=native)
         torch.cuda.synchronize()
     finally:
+        _lib.debug_set_flags(0)
         _lib.set_variant(-1)
     exact, lse_x = oracle.exact64(q, k, v, causal, sc, return_lse=True)
     A = oracle.abs_weighted(q, k, v, causal, sc)

@@ -320,14 +320,12 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   q.lse = ws_l;
   q.out_dtype = TFA_F32;
   q.o_stride[0] = (int64_t)p->H * p->Nq * p->D; q.o_stride[1] = (int64_t)p->Nq * p->D; q.o_stride[2] = p->D;
-  {
-    tfa_fwd_params qp;                                    // GQA decode: one stream of K/V per K/V head (the workspace rows keep their order)
-    if (!(g_dbg_flags & 4096) && pack_gqa_rows(&q, &qp)) q = qp;
-  }
-  if (p->D > 128) {
+  if (p->D > 128 || !one_descriptor(p) || (g_dbg_flags & 8192)) {
     // Head dims 136..256: the one kernel that wide (x4-d256) has no chunk dimension in its grid, so the partial passes are `ns`
     // launches of tfa_fwd over key chunks (kv_offset / nk_total: the causal mask stays against global key positions) — one
-    // launch per chunk instead of one in all, same partials, same merge.
+    // launch per chunk instead of one in all, same partials, same merge.  (b,h) slices of 2 GiB and more (long strided K/V
+    // caches) take the same route: the LDS-DMA kernel below addresses a slice through ONE descriptor, tfa_fwd's il kernels through
+    // windows.  (Debug flag 8192 forces this route: tests compare it with the one-launch form.)
     const int64_t rs_k = p->k_stride[2], rs_v = p->v_stride[2];
     for (int c = 0; c < ns; ++c) {
       tfa_fwd_params qc = q;
@@ -343,6 +341,10 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
       if (st != TFA_OK) return st;
     }
     return tfa_merge(ws_o, ws_l, ns, rows, p->D, rows * p->D, rows, p->out, p->out_dtype, p->lse, stream);
+  }
+  {
+    tfa_fwd_params qp;                                    // GQA decode: one stream of K/V per K/V head (the workspace rows keep their order)
+    if (!(g_dbg_flags & 4096) && pack_gqa_rows(&q, &qp)) q = qp;
   }
   const int variant = tfa::kSplitVariant;                 // the LDS-DMA kernel carries the chunk dimension in its grid
   tfa::KArgs a;

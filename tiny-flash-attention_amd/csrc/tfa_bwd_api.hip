@@ -164,6 +164,11 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   const long long need = ws_bytes(p, &nk_pad, &nq_pad);
   if (p->workspace && (((uintptr_t)p->workspace) & 15)) return TFA_ERR_ALIGN;
   const bool use_ws = p->workspace != nullptr && need > 0 && p->workspace_bytes >= need && !(g_bwd_split & 1) && !wide256 && !big;
+#if defined(TFA_BWD_TRACE)
+  if (g_bwd_split & 4) { a.ws = p->workspace; a.ws_nk = -1; }          // debug build: the fused launch writes per-wave wait cycles into the workspace
+  const bool use_ws_dbg = use_ws && !(g_bwd_split & 4);
+#define use_ws use_ws_dbg
+#endif
   if (use_ws) {
     tfa::BArgs m = a;
     m.ws = p->workspace; m.ws_nk = nk_pad; m.ws_nq = nq_pad;
@@ -223,7 +228,7 @@ extern "C" {
 
 int tfa_bwd(const tfa_bwd_params* p, void* stream) { return run_bwd(p, stream, false); }
 int tfa_bwd_plan(const tfa_bwd_params* p) { return run_bwd(p, nullptr, true); }
-int tfa_debug_bwd_split(int on) { g_bwd_split = on & 3; return TFA_OK; }
+int tfa_debug_bwd_split(int on) { g_bwd_split = on & 7; return TFA_OK; }
 long long tfa_bwd_workspace_bytes(const tfa_bwd_params* p) {
   tfa_bwd_params q;
   if (!p) return TFA_ERR_NULL;

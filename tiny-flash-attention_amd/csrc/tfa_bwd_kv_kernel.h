@@ -216,6 +216,10 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   auto next_tile = [&]() {
     if (++jt_c == t_end) { jt_c = t_begin; ++g_c; }
   };
+#if defined(TFA_BWD_TRACE)   // debug build: cycles each wave spends waiting at the end of an iteration (memory, then barrier)
+  unsigned long long tw_mem = 0, tw_bar = 0;
+  const unsigned long long tw_t0 = __builtin_amdgcn_s_memtime();
+#endif
   int st_next = 1;                                   // stage of tile it+1
   int st_mine = role ? NSTAGE - 1 : 0;               // stage of this wave's tile (role 1: tile it-1)
 #pragma nounroll
@@ -323,11 +327,28 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
         continue;
       }
     }
+#if defined(TFA_BWD_TRACE)
+    {
+      const unsigned long long a0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const unsigned long long a1 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_barrier" ::: "memory");
+      const unsigned long long a2 = __builtin_amdgcn_s_memtime();
+      tw_mem += a1 - a0; tw_bar += a2 - a1;
+    }
+#else
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     st_next = st_next + 1 == NSTAGE ? 0 : st_next + 1;
     st_mine = st_mine + 1 == NSTAGE ? 0 : st_mine + 1;
   }
 
+#if defined(TFA_BWD_TRACE)
+  if (!WS && p.ws != nullptr && lane == 0) {
+    unsigned long long* tr = reinterpret_cast<unsigned long long*>(p.ws) + ((size_t)blockIdx.x * NW + wave) * 4;
+    tr[0] = __builtin_amdgcn_s_memtime() - tw_t0; tr[1] = tw_mem; tr[2] = tw_bar; tr[3] = (unsigned long long)nu;
+  }
+#endif
   // ---- epilogue: role 0 writes dV, role 1 writes dK * scale.  acc[dt][r] = grad[row my_row][32*dt + (r&3) + 8*(r>>2) + 4*hi] ----
   const float osc = role ? p.scale : 1.f;
   void* const gp = role ? p.grad : p.grad2;

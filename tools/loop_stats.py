@@ -45,7 +45,7 @@ def main():
             if n < min_mfma:
                 continue
             c = lambda f: sum(1 for o in ops if f(o))
-            trans = c(lambda o: o in ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32"))
+            trans = c(lambda o: o.split("_e32")[0].split("_e64")[0] in ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32"))
             valu = c(lambda o: o.startswith("v_") and not o.startswith("v_mfma") and not o.startswith("v_readlane") and not o.startswith("v_writelane") and not o.startswith("v_readfirstlane"))
             rows.append((name, len(ops), n, valu - trans, trans, c(lambda o: o.startswith("s_") and o not in ("s_waitcnt", "s_nop", "s_barrier")),
                          c(lambda o: o == "s_waitcnt"), c(lambda o: o == "s_nop"), c(lambda o: o.startswith("ds_read")), c(lambda o: o.startswith("ds_write")),
