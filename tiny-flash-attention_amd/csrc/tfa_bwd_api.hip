@@ -163,12 +163,16 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
   int nk_pad = 0, nq_pad = 0;
   const long long need = ws_bytes(p, &nk_pad, &nq_pad);
   if (p->workspace && (((uintptr_t)p->workspace) & 15)) return TFA_ERR_ALIGN;
-  const bool use_ws = p->workspace != nullptr && need > 0 && p->workspace_bytes >= need && !(g_bwd_split & 1) && !wide256 && !big;
 #if defined(TFA_BWD_TRACE)
-  if (g_bwd_split & 4) { a.ws = p->workspace; a.ws_nk = -1; }          // debug build: the fused launch writes per-wave wait cycles into the workspace
-  const bool use_ws_dbg = use_ws && !(g_bwd_split & 4);
-#define use_ws use_ws_dbg
+  // debug build: with bit 2 of tfa_debug_bwd_split the LAST 64 MiB of the workspace receive the fused launch's per-wave wait cycles
+  constexpr long long kTraceBytes = 64ll << 20;
+  const bool tracing = (g_bwd_split & 4) && p->workspace && p->workspace_bytes >= kTraceBytes;
+  const long long ws_avail = p->workspace_bytes - (tracing ? kTraceBytes : 0);
+  a.tr = tracing ? reinterpret_cast<char*>(p->workspace) + ws_avail : nullptr;
+#else
+  const long long ws_avail = p->workspace_bytes;
 #endif
+  const bool use_ws = p->workspace != nullptr && need > 0 && ws_avail >= need && !(g_bwd_split & 1) && !wide256 && !big;
   if (use_ws) {
     tfa::BArgs m = a;
     m.ws = p->workspace; m.ws_nk = nk_pad; m.ws_nq = nq_pad;

@@ -50,6 +50,9 @@ struct BArgs {
   int big;                   // some slice reaches 2 GiB: the host launches the BIG instantiations
   void* ws;                  // optional dS workspace (tfa_bwd_params::workspace): dS^T[b][query head][ws_nk key rows][ws_nq queries], 16 bit
   int ws_nk, ws_nq;          // padded extents: Nk rounded up to 128, Nq rounded up to 256
+#if defined(TFA_BWD_TRACE)
+  void* tr;                  // debug build (tools/trace_bwd_kv.py): 4 x uint64 per wave of the fused dK/dV launch
+#endif
 };
 
 enum { BWD_DQ = 0, BWD_DK = 1, BWD_DV = 2 };

@@ -344,8 +344,8 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   }
 
 #if defined(TFA_BWD_TRACE)
-  if (!WS && p.ws != nullptr && lane == 0) {
-    unsigned long long* tr = reinterpret_cast<unsigned long long*>(p.ws) + ((size_t)blockIdx.x * NW + wave) * 4;
+  if (p.tr != nullptr && lane == 0) {
+    unsigned long long* tr = reinterpret_cast<unsigned long long*>(p.tr) + ((size_t)blockIdx.x * NW + wave) * 4;
     tr[0] = __builtin_amdgcn_s_memtime() - tw_t0; tr[1] = tw_mem; tr[2] = tw_bar; tr[3] = (unsigned long long)nu;
   }
 #endif

@@ -10,6 +10,7 @@ from tiny_flash_attention_amd import _lib, ops
 CFG = {"cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096, 128, torch.bfloat16, False), "cfg4": (1, 16, 16384, 128, torch.bfloat16, False)}
 ap = argparse.ArgumentParser()
 ap.add_argument("--cfg", default="cfg3")
+ap.add_argument("--ws", action="store_true", help="the workspace (5-GEMM) form: the same launch also stores dS")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 B, H, N, D, dt, causal = CFG[a.cfg]
@@ -20,7 +21,8 @@ out, lse = ops.flash_attn_fwd(q, k, v, causal, sc)
 dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
 delta = torch.empty_like(lse)
 p = ops.make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, causal, sc)
-ws = torch.zeros((64 << 20,), dtype=torch.uint8, device=dev)
+need = ops.bwd_workspace_bytes(p) if a.ws else 0
+ws = torch.zeros((need + (64 << 20),), dtype=torch.uint8, device=dev)          # the trace lives in the last 64 MiB
 p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
 _lib.debug_bwd_split(4)
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -28,11 +30,11 @@ for _ in range(3):
     _lib.check(_lib.lib().tfa_bwd(C.byref(p), s))
 torch.cuda.synchronize()
 _lib.debug_bwd_split(0)
-t = ws.view(torch.int64).cpu().view(-1, 4)
+t = ws[need:].view(torch.int64).cpu().view(-1, 4)
 nwg = (N // 128) * B * H if True else 0
 t = t[: nwg * 8].view(nwg, 8, 4).double()
 tot, mem, bar, nu = t[..., 0], t[..., 1], t[..., 2], t[..., 3]
-print(f"{a.cfg}: {nwg} workgroups x 8 waves; wave life mean {tot.mean():.0f} cycles (100 MHz ticks x?), tiles per workgroup {nu.min():.0f}..{nu.max():.0f}")
+print(f"{a.cfg}{' (workspace form)' if a.ws else ''}: {nwg} workgroups x 8 waves; wave life mean {tot.mean():.0f} cycles (100 MHz ticks x?), tiles per workgroup {nu.min():.0f}..{nu.max():.0f}")
 for role, sl in (("role 0 (waves 0-3: S, P, dV)", slice(0, 4)), ("role 1 (waves 4-7: dP, dS, dK)", slice(4, 8))):
     T, M, Bq = tot[:, sl].sum(), mem[:, sl].sum(), bar[:, sl].sum()
     print(f"  {role}: memory wait {100 * M / T:5.1f} %   barrier wait {100 * Bq / T:5.1f} %   per tile: life {T / nu[:, sl].sum():.1f}, memory {M / nu[:, sl].sum():.1f}, barrier {Bq / nu[:, sl].sum():.1f} ticks")
