@@ -1,5 +1,7 @@
-// tfa_bwd_api.hip — extern "C" backward entry points of include/tfa.h: validate, fill kernel arguments, launch
-// delta -> dQ -> dK -> dV on the caller's stream (see tfa_bwd_kernel.h for the kernels).
+// tfa_bwd_api.hip — extern "C" backward entry points of include/tfa.h: validate, fill kernel arguments, launch on the caller's stream
+//   delta -> dQ (tfa_bwd_kernel.h) -> fused dK/dV (tfa_bwd_kv_kernel.h)                       the default: 7 GEMM units
+//   delta -> fused dK/dV that also stores dS -> dQ = dS.K (tfa_bwd_dq_kernel.h)               with tfa_bwd_params::workspace: 5 units
+//   delta -> dQ -> dK -> dV (tfa_bwd_kernel.h, three single-gradient launches)                head dims above 128, and the debug form
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>

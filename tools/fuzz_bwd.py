@@ -32,10 +32,13 @@ for it in range(a.n):
     q, k, v, dout = mk(Nq, H), mk(Nk, Hk), mk(Nk, Hk), mk(Nq, H)
     sc = rng.choice([1.0 / math.sqrt(D), 0.05, 0.2])
     out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout)
-    mode = rng.choice(["default", "default", "workspace", "split"])     # tfa_bwd's three forms (tests/test_bwd_gpu.py: MODES)
-    _lib.debug_bwd_split(mode == "split")
+    mode = rng.choice(["default", "default", "workspace", "split", "windowed"])     # tfa_bwd's three forms (tests/test_bwd_gpu.py: MODES) + the >= 2 GiB instantiations, forced
+    if mode == "windowed" and D > 128:
+        mode = "default"
+    f32 = rng.random() < 0.25                          # fp32 gradients
+    _lib.debug_bwd_split({"split": 1, "windowed": 2}.get(mode, 0))
     try:
-        dq, dk, dv = ops.flash_attn_bwd(q, k, v, out, lse, dout, causal, sc, layout=layout, workspace=True if mode == "workspace" else None)
+        dq, dk, dv = ops.flash_attn_bwd(q, k, v, out, lse, dout, causal, sc, layout=layout, grad_f32=f32, workspace=True if mode == "workspace" else None)
     finally:
         _lib.debug_bwd_split(False)
     tr = (lambda t: t) if layout == "bhnd" else (lambda t: t.transpose(1, 2))
@@ -58,6 +61,6 @@ for it in range(a.n):
             msg.append(f"{name} max|d|={d:.3e} > {bar:.3e}")
     if msg:
         bad += 1
-        print(f"FAIL B{B} H{H} Hk{Hk} Nq{Nq} Nk{Nk} D{D} {dt} causal={causal} {layout} {mode} sc={sc:.3f}: " + "; ".join(msg), flush=True)
+        print(f"FAIL B{B} H{H} Hk{Hk} Nq{Nq} Nk{Nk} D{D} {dt} causal={causal} {layout} {mode}{' f32' if f32 else ''} sc={sc:.3f}: " + "; ".join(msg), flush=True)
 print(f"{a.n - bad}/{a.n} ok")
 sys.exit(1 if bad else 0)

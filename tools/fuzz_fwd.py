@@ -57,18 +57,29 @@ for it in range(a.n):
         full = torch.empty(shp(n, h)[:3] + (D + pad,), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(dt)
         return full[..., :D] if pad else full
     q, k, v = mk(Nq, H), mk(Nk, Hk), mk(Nk, Hk)
-    mode = "auto" if a.decode else rng.choice(["16", "16", "16", "f32", "chunks"])
+    mode = "auto" if a.decode else rng.choice(["16", "16", "16", "f32", "chunks", "native", "native-chunks", "exact"])
     sc = rng.choice([1.0 / math.sqrt(D), 0.05, 0.3])
     if mode == "f32":                                    # fp32 debug output
         out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout, out_f32=True)
     elif mode == "chunks" and layout == "bhnd" and Nk >= 128 and D <= 128:   # python-driven partial passes + tfa_merge
         out, lse = ops.flash_attn_fwd_splitkv(q, k, v, causal, sc, splits=rng.choice([2, 3, 5]), native=False)
+    elif mode in ("native", "native-chunks") and layout == "bhnd" and not pad and Nk >= 128:   # tfa_fwd_splitkv: one launch, or (forced) one per chunk
+        if mode == "native-chunks":
+            _lib.debug_set_flags(8192)
+        try:
+            out, lse = ops.flash_attn_fwd_splitkv(q, k, v, causal, sc, splits=rng.choice([2, 3, 5]), native=True)
+        finally:
+            _lib.debug_set_flags(0)
+    elif mode == "exact" and D <= 128:                   # TFA_FWD_EXACT_MAX: the exact-running-max kernel
+        out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout, exact_max=True)
     else:
         out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout, auto_split=a.decode)
     name = _lib.variant_name(_lib.variant_for(B, H, Hk, Nq, Nk, D, causal)).split(" ")[0]
     if a.decode:
         import ctypes as C
         name = "splits=%d" % _lib.lib().tfa_fwd_suggest_splits(C.byref(ops.make_params(q, k, v, out, lse, causal, sc)))
+    if mode in ("native", "native-chunks", "exact"):
+        name = mode
     used[name] = used.get(name, 0) + 1
     tr = (lambda t: t) if layout == "bhnd" else (lambda t: t.transpose(1, 2))
     qf, kf, vf = tr(q).float(), tr(k).float().repeat_interleave(H // Hk, 1), tr(v).float().repeat_interleave(H // Hk, 1)
