@@ -1,6 +1,6 @@
 // tfa_launch.h — host-side dispatch table shared by the per-(dtype, head-dim) instantiation units.
 #pragma once
-// The product library carries seven kernels only (kDefaultVariant, kSmallGridVariant, kKSplitVariant, kKSplitPairVariant, kSplitVariant and the two x4 ones below); every
+// The product library carries six kernels only (kDefaultVariant, kSmallGridVariant, kKSplitVariant, kKSplitPairVariant, kSplitVariant and kX4D256Variant); every
 // other entry of kVariants is a measured dead end or an A/B arm kept for the record and is compiled only with
 // -DTFA_EXPERIMENTAL (make EXPERIMENTAL=1).  Without the flag those variant numbers are rejected (TFA_ERR_VARIANT).
 #include <hip/hip_runtime.h>
@@ -69,7 +69,7 @@ static const Variant kVariants[] = {
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
 constexpr int kSmallGridVariant = 32;     // il4-pair-epi (128-row query blocks, two workgroups per CU)
-constexpr int kX4Variant = 33;            // il-x4-pair-epi
+constexpr int kX4Variant = 33;            // il-x4-pair-epi (EXPERIMENTAL builds: the x4 kernel at head dims <= 128)
 constexpr int kX4D256Variant = 34;        // x4-d256-pair: the only kernel for head dims above 128
 constexpr int kSeamVariant = 35;          // il8-pair-dmaspread-epi-seam
 constexpr int kKSplitVariant = 36;        // il8-ksplit-epi: grids of at most one 128-row block per CU
@@ -99,7 +99,7 @@ static inline bool variant_built(int variant) {
 #if defined(TFA_EXPERIMENTAL)
   return true;
 #else
-  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant || variant == kX4Variant || variant == kX4D256Variant ||
+  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant || variant == kX4D256Variant ||
          variant == kKSplitVariant || variant == kKSplitPairVariant;
 #endif
 }
