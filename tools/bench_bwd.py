@@ -8,7 +8,10 @@ sys.path.insert(0, ROOT)
 from tiny_flash_attention_amd import _lib, ops
 CFG = {"cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096, 128, torch.bfloat16, False),
        "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg2": (4, 8, 1024, 64, torch.float16, False),
-       "cfg5": (8, 32, 4096, 128, torch.bfloat16, True)}
+       "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),
+       # does the dS workspace pay when it fits the 256 MB memory-side cache?  dS = B*H*N*N*2 bytes: 134 MB, 268 MB, 1.07 GB
+       "m1": (1, 16, 2048, 128, torch.bfloat16, False), "m2": (2, 16, 2048, 128, torch.bfloat16, False), "m8": (8, 16, 2048, 128, torch.bfloat16, False),
+       "n1": (1, 64, 1024, 128, torch.bfloat16, False), "n8": (8, 64, 1024, 128, torch.bfloat16, False)}
 ap = argparse.ArgumentParser()
 ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4,cfg2")
 ap.add_argument("--iters", type=int, default=20)
