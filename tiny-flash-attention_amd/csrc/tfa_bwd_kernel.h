@@ -21,6 +21,7 @@
 // the issue-interleaving of tfa_fwd_kernel_il.h is the next step for this kernel.
 #pragma once
 #include "tfa_fwd_kernel_dma.h"
+#include "tfa_bwd_acc_regs.h"
 
 namespace tfa {
 
@@ -248,11 +249,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
     delta_lane = p.delta[si];
   }
 
-  f32x16 acc[DT];
+  constexpr bool OWN_ACC = NW == 4;                  // head dims above 128: the accumulators are the hand-owned a[0:127] (tfa_bwd_acc_regs.h)
+  f32x16 acc[OWN_ACC ? 1 : DT];
+  if (OWN_ACC) g_zero();
+  else {
 #pragma unroll
-  for (int d = 0; d < DT; ++d)
+    for (int d = 0; d < (OWN_ACC ? 1 : DT); ++d)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  }
 
   const int k_rd_base = qi * (D * 2);
   const int k_rd_swz = UNI ? u_swz<D>(qi) : k_swz<D>(qi);
@@ -269,11 +274,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
 
   if (nu > 0) dma_issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (one wave per SIMD, head dims above 128: the resident fragments live in AccVGPRs — the MFMAs read them there; pinned in
+  //  architectural VGPRs hipcc parks them in AccVGPRs anyway and copies four dwords back in front of every MFMA)
 #pragma unroll
-  for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(r1f[s]));
+  for (int s = 0; s < DS; ++s) {
+    if (NW == 4) asm volatile("" : "+a"(r1f[s])); else asm volatile("" : "+v"(r1f[s]));
+  }
   if (NEED_DP) {
 #pragma unroll
-    for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(r2f[s]));
+    for (int s = 0; s < DS; ++s) {
+      if (NW == 4) asm volatile("" : "+a"(r2f[s])); else asm volatile("" : "+v"(r2f[s]));
+    }
   }
   asm volatile("s_barrier" ::: "memory");
 
@@ -311,11 +322,38 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      if constexpr (NW == 4) {
+        // resident fragments in AccVGPRs, S / dP in VGPRs (Elem::mfma_bacc).  The MFMAs are asm statements, which hipcc keeps in
+        // program order and does not pipeline LDS reads around: the fragments are read in groups of eight k-steps, one group ahead.
+        constexpr int GK = 8, NG = DS / GK;
+        X8 fa[2][GK], fb[NEED_DP ? 2 : 1][NEED_DP ? GK : 1];
+        auto rd = [&](int g, int buf) {
 #pragma unroll
-      for (int sl = 0; sl < DS; ++sl) {
-        const int off = k_rd_base + t * 32 * (D * 2) + (((2 * sl + hi) ^ k_rd_swz) << 4);
-        s = E::mfma(__builtin_bit_cast(X8, lds_read_b128(img0, off)), r1f[sl], s);
-        if (NEED_DP) dp = E::mfma(__builtin_bit_cast(X8, lds_read_b128(img1, off)), r2f[sl], dp);
+          for (int i = 0; i < GK; ++i) {
+            const int off = k_rd_base + t * 32 * (D * 2) + (((2 * (g * GK + i) + hi) ^ k_rd_swz) << 4);
+            fa[buf][i] = __builtin_bit_cast(X8, lds_read_b128(img0, off));
+            if (NEED_DP) fb[buf][i] = __builtin_bit_cast(X8, lds_read_b128(img1, off));
+          }
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) rd(g + 1, (g + 1) & 1);
+#pragma unroll
+          for (int i = 0; i < GK; ++i) {
+            E::mfma_bacc(fa[g & 1][i], r1f[g * GK + i], s);
+            if (NEED_DP) E::mfma_bacc(fb[g & 1][i], r2f[g * GK + i], dp);
+          }
+        }
+        mfma_drain(s);
+        if (NEED_DP) asm volatile("" : "+v"(dp));    // (dP's last MFMA sits in front of the drain as well: asm statements keep their order)
+      } else {
+#pragma unroll
+        for (int sl = 0; sl < DS; ++sl) {
+          const int off = k_rd_base + t * 32 * (D * 2) + (((2 * sl + hi) ^ k_rd_swz) << 4);
+          s = E::mfma(__builtin_bit_cast(X8, lds_read_b128(img0, off)), r1f[sl], s);
+          if (NEED_DP) dp = E::mfma(__builtin_bit_cast(X8, lds_read_b128(img1, off)), r2f[sl], dp);
+        }
       }
       // ---- statistics of the 16 tile rows this lane sees (dK/dV) --------------------------------------------------
       float lse2[16], dl[16];
@@ -363,23 +401,40 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
         pk[t * 2 + (r >> 3)][r & 7] = (T)y;
       }
       // ---- GEMM-II for the two 16-row slots of this half -----------------------------------------------------------
-#pragma unroll
-      for (int sl = 2 * t; sl < 2 * t + 2; ++sl)
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-          s16x4 lo, hh;
-          if (UNI) {
-            const int c = 4 * d + tr_clo;
-            lo = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b1 + ((c ^ tr_s1) << 4));
-            hh = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b2 + ((c ^ tr_s2) << 4));
-          } else {
+      auto rd_tr = [&](int sl, int d) -> X8 {
+        s16x4 lo, hh;
+        if (UNI) {
+          const int c = 4 * d + tr_clo;
+          lo = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b1 + ((c ^ tr_s1) << 4));
+          hh = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b2 + ((c ^ tr_s2) << 4));
+        } else {
           const char* a = imgt + v_rd_base + (sl * 2 * DT << 9) + (d << 9);
           lo = lds_read_tr16_b64(a);
           hh = lds_read_tr16_b64(a + 256);
-          }
-          s16x8 vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
-          acc[d] = E::mfma(__builtin_bit_cast(X8, vf), pk[sl], acc[d]);
         }
+        s16x8 vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(X8, vf);
+      };
+      if constexpr (OWN_ACC) {
+        // (asm MFMAs again: the DT transposed fragments of a 16-row slot are read one slot ahead of the MFMAs that use them)
+        X8 vt[2][DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) vt[0][d] = rd_tr(2 * t, d);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (k == 0) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) vt[1][d] = rd_tr(2 * t + 1, d);
+          }
+#pragma unroll
+          for (int d = 0; d < DT; ++d) g_mfma_d<T>(d, vt[k][d], pk[2 * t + k]);
+        }
+      } else {
+#pragma unroll
+        for (int sl = 2 * t; sl < 2 * t + 2; ++sl)
+#pragma unroll
+          for (int d = 0; d < DT; ++d) acc[d] = E::mfma(rd_tr(sl, d), pk[sl], acc[d]);
+      }
     }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -387,6 +442,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
 
   // ---- epilogue: acc[dt][r] = grad[row my_row][32*dt + (r&3) + 8*(r>>2) + 4*hi] ----------------------------------------
   const float osc = (MODE == BWD_DV) ? 1.f : p.scale;
+  float gout[OWN_ACC ? DT : 1][16];                  // OWN_ACC: the accumulators read out of a[0:127]
+  if constexpr (OWN_ACC) {
+#pragma unroll
+    for (int d = 0; d < DT; ++d) g_read_d(d, gout[d]);
+  }
+  auto ga = [&](int d, int r) -> float { return OWN_ACC ? gout[OWN_ACC ? d : 0][r] : acc[OWN_ACC ? 0 : d][r]; };
   if (F32OUT) {
     float* gb = reinterpret_cast<float*>(p.grad) + b * p.gs_b + hr * p.gs_h;
     auto g_rs = BIG ? rsrc_at(gb, p.g_full, (unsigned long long)r0 * (unsigned long long)p.gs_n * 4ull) : __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, p.g_bytes, 0x00020000);
@@ -395,7 +456,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        f32x4 v4 = {acc[d][4 * g4 + 0] * osc, acc[d][4 * g4 + 1] * osc, acc[d][4 * g4 + 2] * osc, acc[d][4 * g4 + 3] * osc};
+        f32x4 v4 = {ga(d, 4 * g4 + 0) * osc, ga(d, 4 * g4 + 1) * osc, ga(d, 4 * g4 + 2) * osc, ga(d, 4 * g4 + 3) * osc};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), g_rs, d * 32 + g4 * 8 + hi * 4 < p.dv ? goff + (d * 32 + g4 * 8) * 4 : (int)TFA_OOB, 0, 0);
       }
   } else {
@@ -407,7 +468,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        t4 v4 = {(T)(acc[d][4 * g4 + 0] * osc), (T)(acc[d][4 * g4 + 1] * osc), (T)(acc[d][4 * g4 + 2] * osc), (T)(acc[d][4 * g4 + 3] * osc)};
+        t4 v4 = {(T)(ga(d, 4 * g4 + 0) * osc), (T)(ga(d, 4 * g4 + 1) * osc), (T)(ga(d, 4 * g4 + 2) * osc), (T)(ga(d, 4 * g4 + 3) * osc)};
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), g_rs, d * 32 + g4 * 8 + hi * 4 < p.dv ? goff + (d * 32 + g4 * 8) * 2 : (int)TFA_OOB, 0, 0);
       }
   }

@@ -79,12 +79,27 @@ template <> struct Elem<__bf16> {
   static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
+  // c += a . b with the B operand read from AccVGPRs and the accumulator in architectural VGPRs — for kernels whose register
+  // budget is "accumulators and resident operands in AccVGPRs, everything VALU touches in VGPRs" (one wave per SIMD, 512
+  // registers).  hipcc picks ONE form for every MFMA of a kernel; with the builtin the VALU-consumed accumulators land in AccVGPRs
+  // too and everything is copied around.  Inline asm: nothing pads the MFMA -> VALU hazard behind it (mfma_drain below).
+  static __device__ __forceinline__ void mfma_bacc(x8 a, x8 b, f32x16& c) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+  }
+
 };
+// wait states between the last asm MFMA that wrote c and the first instruction that reads it (8-pass MFMA: 12)
+static __device__ __forceinline__ void mfma_drain(f32x16& c) { asm volatile("s_nop 12" : "+v"(c)); }
 template <> struct Elem<_Float16> {
   using x8 = f16x8;
   static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
+  // (see Elem<__bf16>::mfma_bacc)
+  static __device__ __forceinline__ void mfma_bacc(x8 a, x8 b, f32x16& c) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+  }
+
 };
 
 typedef __attribute__((address_space(3))) char lds_char;

@@ -11,7 +11,10 @@ CFG = {"cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096,
        "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),
        # does the dS workspace pay when it fits the 256 MB memory-side cache?  dS = B*H*N*N*2 bytes: 134 MB, 268 MB, 1.07 GB
        "m1": (1, 16, 2048, 128, torch.bfloat16, False), "m2": (2, 16, 2048, 128, torch.bfloat16, False), "m8": (8, 16, 2048, 128, torch.bfloat16, False),
-       "n1": (1, 64, 1024, 128, torch.bfloat16, False), "n8": (8, 64, 1024, 128, torch.bfloat16, False)}
+       "n1": (1, 64, 1024, 128, torch.bfloat16, False), "n8": (8, 64, 1024, 128, torch.bfloat16, False),
+       # head dims above 128 (one wave per SIMD, three single-gradient launches)
+       "d256c": (4, 8, 4096, 256, torch.bfloat16, True), "d256": (4, 8, 4096, 256, torch.bfloat16, False), "d192c": (4, 16, 4096, 192, torch.bfloat16, True),
+       "d256h": (4, 8, 4096, 256, torch.float16, True)}
 ap = argparse.ArgumentParser()
 ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4,cfg2")
 ap.add_argument("--iters", type=int, default=20)
