@@ -23,15 +23,20 @@ template <typename T> struct GMfma;
 template <> struct GMfma<__bf16> { static constexpr bool bf = true; };
 template <> struct GMfma<_Float16> { static constexpr bool bf = false; };
 
-#define TFA_G_CASE(DI, LO, HI)                                                                                                            \
-  if constexpr (DI == LO / 16) {                                                                                                          \
-    if constexpr (GMfma<T>::bf)                                                                                                           \
-      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[" #LO ":" #HI "], %0, %1, a[" #LO ":" #HI "]" ::"v"(a), "v"(b) : TFA_G_CLOB);   \
-    else                                                                                                                                  \
-      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[" #LO ":" #HI "], %0, %1, a[" #LO ":" #HI "]" ::"v"(a), "v"(b) : TFA_G_CLOB);    \
+#define TFA_G_ASM(PRE, OP, LO, HI) asm volatile(PRE OP " a[" #LO ":" #HI "], %0, %1, a[" #LO ":" #HI "]" ::"v"(a), "v"(b) : TFA_G_CLOB)
+#define TFA_G_CASE(DI, LO, HI)                                                                 \
+  if constexpr (DI == LO / 16) {                                                               \
+    if constexpr (GMfma<T>::bf) {                                                              \
+      if constexpr (PAD) TFA_G_ASM("s_nop 1\n\t", "v_mfma_f32_32x32x16_bf16", LO, HI);         \
+      else TFA_G_ASM("", "v_mfma_f32_32x32x16_bf16", LO, HI);                                  \
+    } else {                                                                                   \
+      if constexpr (PAD) TFA_G_ASM("s_nop 1\n\t", "v_mfma_f32_32x32x16_f16", LO, HI);          \
+      else TFA_G_ASM("", "v_mfma_f32_32x32x16_f16", LO, HI);                                   \
+    }                                                                                          \
   }
-// grad[column tile DI] += A . B
-template <typename T, int DI, typename X8> static __device__ __forceinline__ void g_mfma(X8 a, X8 b) {
+// grad[column tile DI] += A . B.  PAD: the two wait states a VALU-written operand needs in front of the MFMA (the first MFMA behind
+// the code that packed B; the others read operands that LDS reads or earlier VALU code delivered — the build's audit checks it)
+template <typename T, int DI, bool PAD, typename X8> static __device__ __forceinline__ void g_mfma(X8 a, X8 b) {
   TFA_G_CASE(DI, 0, 15)
   TFA_G_CASE(DI, 16, 31)
   TFA_G_CASE(DI, 32, 47)
@@ -41,15 +46,15 @@ template <typename T, int DI, typename X8> static __device__ __forceinline__ voi
   TFA_G_CASE(DI, 96, 111)
   TFA_G_CASE(DI, 112, 127)
 }
-template <typename T, typename X8> static __device__ __forceinline__ void g_mfma_d(int d, X8 a, X8 b) {   // d folds to a constant (unrolled loops)
-  if (d == 0) g_mfma<T, 0>(a, b);
-  else if (d == 1) g_mfma<T, 1>(a, b);
-  else if (d == 2) g_mfma<T, 2>(a, b);
-  else if (d == 3) g_mfma<T, 3>(a, b);
-  else if (d == 4) g_mfma<T, 4>(a, b);
-  else if (d == 5) g_mfma<T, 5>(a, b);
-  else if (d == 6) g_mfma<T, 6>(a, b);
-  else g_mfma<T, 7>(a, b);
+template <typename T, bool PAD, typename X8> static __device__ __forceinline__ void g_mfma_d(int d, X8 a, X8 b) {   // d folds to a constant (unrolled loops)
+  if (d == 0) g_mfma<T, 0, PAD>(a, b);
+  else if (d == 1) g_mfma<T, 1, PAD>(a, b);
+  else if (d == 2) g_mfma<T, 2, PAD>(a, b);
+  else if (d == 3) g_mfma<T, 3, PAD>(a, b);
+  else if (d == 4) g_mfma<T, 4, PAD>(a, b);
+  else if (d == 5) g_mfma<T, 5, PAD>(a, b);
+  else if (d == 6) g_mfma<T, 6, PAD>(a, b);
+  else g_mfma<T, 7, PAD>(a, b);
 }
 static __device__ __forceinline__ void g_zero() {
   asm volatile(".irp r," TFA_G_LIST "\n\tv_accvgpr_write_b32 a[\\r], 0\n\t.endr" ::: TFA_G_CLOB);

@@ -341,8 +341,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
           if (g + 1 < NG) rd(g + 1, (g + 1) & 1);
 #pragma unroll
           for (int i = 0; i < GK; ++i) {
-            E::mfma_bacc(fa[g & 1][i], r1f[g * GK + i], s);
-            if (NEED_DP) E::mfma_bacc(fb[g & 1][i], r2f[g * GK + i], dp);
+            if (g == 0 && i == 0) {                  // (s and dp were just zeroed by VALU moves: the padded form)
+              E::template mfma_bacc<true>(fa[0][0], r1f[0], s);
+              if (NEED_DP) E::template mfma_bacc<true>(fb[0][0], r2f[0], dp);
+            } else {
+              E::template mfma_bacc<false>(fa[g & 1][i], r1f[g * GK + i], s);
+              if (NEED_DP) E::template mfma_bacc<false>(fb[g & 1][i], r2f[g * GK + i], dp);
+            }
           }
         }
         mfma_drain(s);
@@ -427,7 +432,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
             for (int d = 0; d < DT; ++d) vt[1][d] = rd_tr(2 * t + 1, d);
           }
 #pragma unroll
-          for (int d = 0; d < DT; ++d) g_mfma_d<T>(d, vt[k][d], pk[2 * t + k]);
+          for (int d = 0; d < DT; ++d) {
+            if (d == 0) g_mfma_d<T, true>(d, vt[k][d], pk[2 * t + k]);
+            else g_mfma_d<T, false>(d, vt[k][d], pk[2 * t + k]);
+          }
         }
       } else {
 #pragma unroll

@@ -83,8 +83,10 @@ template <> struct Elem<__bf16> {
   // budget is "accumulators and resident operands in AccVGPRs, everything VALU touches in VGPRs" (one wave per SIMD, 512
   // registers).  hipcc picks ONE form for every MFMA of a kernel; with the builtin the VALU-consumed accumulators land in AccVGPRs
   // too and everything is copied around.  Inline asm: nothing pads the MFMA -> VALU hazard behind it (mfma_drain below).
-  static __device__ __forceinline__ void mfma_bacc(x8 a, x8 b, f32x16& c) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+  // PAD: the two wait states a VALU-written operand (the freshly zeroed c) needs in front of the MFMA.
+  template <bool PAD> static __device__ __forceinline__ void mfma_bacc(x8 a, x8 b, f32x16& c) {
+    if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
   }
 
 };
@@ -96,8 +98,9 @@ template <> struct Elem<_Float16> {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
   // (see Elem<__bf16>::mfma_bacc)
-  static __device__ __forceinline__ void mfma_bacc(x8 a, x8 b, f32x16& c) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+  template <bool PAD> static __device__ __forceinline__ void mfma_bacc(x8 a, x8 b, f32x16& c) {
+    if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
   }
 
 };
