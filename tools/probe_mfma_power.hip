@@ -47,6 +47,37 @@ __global__ __launch_bounds__(512, 2) void spin(const u32x4* src, float* sink, in
   if (s == 123.456f) sink[tid] = s;
 }
 
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+// the same stream with v_mfma_f32_16x16x32_bf16 (16 KFLOP per instruction, a quarter of the accumulator registers per MFMA):
+// does the other tile shape sustain more under the cap?  16 accumulators round-robin, 64 MFMAs per iteration = the same flops.
+template <int BREUSE>
+__global__ __launch_bounds__(512, 2) void spin16(const u32x4* src, float* sink, int iters) {
+  const int tid = blockIdx.x * 512 + threadIdx.x;
+  bf16x8 a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = __builtin_bit_cast(bf16x8, src[(tid * 16 + i) & 0xfffff]);
+    b[i] = __builtin_bit_cast(bf16x8, src[(tid * 16 + 8 + i) & 0xfffff]);
+  }
+  f32x4 c[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[k][r] = 0.f;
+#pragma nounroll
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 64; ++m)
+      c[m & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m & 7], b[(m / BREUSE) & 7], c[m & 15], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s += c[k][r];
+  if (s == 123.456f) sink[tid] = s;
+}
+
 static float gauss() {
   const float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = (rand() + 1.0f) / (RAND_MAX + 2.0f);
   return sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
@@ -71,16 +102,18 @@ int main(int argc, char** argv) {
       h[i] = (unsigned short)((u + 0x7fff + ((u >> 16) & 1)) >> 16);
     }
     hipMemcpy(src, h.data(), n16 * 2, hipMemcpyHostToDevice);
-    for (int br = 0; br < 3; ++br) {
-      const int breuse = 1 << br;
+    for (int br = 0; br < 4; ++br) {
+      const int breuse = br < 3 ? 1 << br : 2;
+      const bool shape16 = br == 3;                // fourth arm: the 16x16x32 instruction, B reuse 2
       // idle gap so that a power sampler can tell the arms apart
       std::this_thread::sleep_for(std::chrono::milliseconds(700));
-      printf("ARM_BEGIN data=%s breuse=%d\n", data == 0 ? "normal(0,0.5)" : "zeros", breuse); fflush(stdout);
+      printf("ARM_BEGIN data=%s breuse=%d%s\n", data == 0 ? "normal(0,0.5)" : "zeros", breuse, shape16 ? " 16x16x32" : ""); fflush(stdout);
       const auto t0 = std::chrono::steady_clock::now();
       double best = 0, last = 0;
       while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         hipEventRecord(e0);
         for (int rep = 0; rep < 4; ++rep) {
+          if (shape16) { hipLaunchKernelGGL(spin16<2>, dim3(grid), dim3(512), 0, 0, src, sink, iters); continue; }
           if (breuse == 1) hipLaunchKernelGGL(spin<1>, dim3(grid), dim3(512), 0, 0, src, sink, iters);
           if (breuse == 2) hipLaunchKernelGGL(spin<2>, dim3(grid), dim3(512), 0, 0, src, sink, iters);
           if (breuse == 4) hipLaunchKernelGGL(spin<4>, dim3(grid), dim3(512), 0, 0, src, sink, iters);
@@ -92,7 +125,7 @@ int main(int argc, char** argv) {
         last = 4 * flops / (ms * 1e-3) / 1e12;
         if (last > best) best = last;
       }
-      printf("ARM_END data=%s breuse=%d  sustained %.1f TFLOP/s (last batch; best %.1f)\n", data == 0 ? "normal(0,0.5)" : "zeros", breuse, last, best);
+      printf("ARM_END data=%s breuse=%d%s  sustained %.1f TFLOP/s (last batch; best %.1f)\n", data == 0 ? "normal(0,0.5)" : "zeros", breuse, shape16 ? " 16x16x32" : "", last, best);
       fflush(stdout);
     }
   }
