@@ -76,7 +76,10 @@ template <int D> static __device__ __forceinline__ int u_swz(int row) {
 // over the workgroup's resident rows, one over its gradient rows — and the 32-bit offsets are window-relative.  Its own instantiation
 // (a fresh descriptor per tile costs scalar work and wait states), launched only when a slice needs it; dQ mode only (the fused
 // dK/dV launch has its own).
-template <typename T, int D, int MODE, bool CAUSAL, bool F32OUT, bool UNI = false, int NW = 8, bool BIG = false>
+// DVB (256-wide kernels only): 32-wide column blocks that can hold valid head-dim columns — ceil(head dim / 32) = 5..8.  The LDS images
+// and every address stay 256 wide (the columns beyond the head dim are the descriptors' zeros); the GEMM loops run over the valid
+// blocks only: at D = 160 / 192 / 224 that is 5/8, 6/8, 7/8 of the matrix work, fragment registers and LDS reads.
+template <typename T, int D, int MODE, bool CAUSAL, bool F32OUT, bool UNI = false, int NW = 8, bool BIG = false, int DVB = D / 32>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BArgs p) {
   static_assert(!BIG || MODE == BWD_DQ, "BIG: the dQ launch");
   using E = Elem<T>;
@@ -87,8 +90,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
   constexpr int TILE_BYTES = BN * D * 2;
   constexpr int PIECES = TILE_BYTES / 1024;
   constexpr int PPW = PIECES / NW;
-  constexpr int DS = D / 16;
-  constexpr int DT = D / 32;
+  static_assert(DVB == D / 32 || (NW == 4 && DVB >= 1 && DVB < D / 32), "DVB < D/32 exists for the 256-wide one-wave-per-SIMD form only");
+  constexpr int DS = 2 * DVB;                      // k-steps of 16 columns (GEMM-I), resident fragments per tensor
+  constexpr int DT = DVB;                          // 32-column tiles of the gradient (GEMM-II)
+  constexpr int DT_L = D / 32;                     // ... as the LDS layouts count them
   constexpr bool KEYS_RES = MODE != BWD_DQ;        // resident rows are keys
   constexpr bool NEED_DP = MODE != BWD_DV;
   constexpr int NIMG = (UNI || MODE == BWD_DV) ? 2 : 3;   // LDS images per tile
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
       } else {                                       // V layout
         const int o = pc * 1024 + lane * 16;
         const int sub = o >> 9, R = (o >> 6) & 7, pcs = (o >> 4) & 3;
-        const int dt = sub % DT, sh = sub / DT;
+        const int dt = sub % DT_L, sh = sub / DT_L;
         const int row = 16 * (sh >> 1) + 4 * (sh & 1) + 8 * (R >> 2) + (R & 3);
         src[img][i] = (dt * 4 + pcs) * 8 < p.dv ? row * sn * 2 + ((dt * 4 + pcs) << 4) : (int)TFA_OOB;
       }
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
   const int k_rd_base = qi * (D * 2);
   const int k_rd_swz = UNI ? u_swz<D>(qi) : k_swz<D>(qi);
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-  const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
+  const int v_rd_base = (hi * DT_L << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
   // UNI transpose reads: this lane addresses 4 consecutive d (8 bytes) of tile row 16*sl + tr_row (first read) and
   // 16*sl + tr_row + 8 (second read); chunk = 4*dtile + tr_clo, XOR-swizzled by the row
   const int tr_row = 4 * hi + (i16 >> 2);
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
       if constexpr (NW == 4) {
         // resident fragments in AccVGPRs, S / dP in VGPRs (Elem::mfma_bacc).  The MFMAs are asm statements, which hipcc keeps in
         // program order and does not pipeline LDS reads around: the fragments are read in groups of eight k-steps, one group ahead.
-        constexpr int GK = 8, NG = DS / GK;
+        constexpr int GK = DVB, NG = 2;                        // two groups of DVB k-steps
         X8 fa[2][GK], fb[NEED_DP ? 2 : 1][NEED_DP ? GK : 1];
         auto rd = [&](int g, int buf) {
 #pragma unroll
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
           lo = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b1 + ((c ^ tr_s1) << 4));
           hh = lds_read_tr16_b64(imgt + sl * 16 * (D * 2) + tr_b2 + ((c ^ tr_s2) << 4));
         } else {
-          const char* a = imgt + v_rd_base + (sl * 2 * DT << 9) + (d << 9);
+          const char* a = imgt + v_rd_base + (sl * 2 * DT_L << 9) + (d << 9);
           lo = lds_read_tr16_b64(a);
           hh = lds_read_tr16_b64(a + 256);
         }

@@ -19,6 +19,9 @@
 namespace tfa {
 template <typename T, int D>
 hipError_t launch_bwd(const BArgs& a, int mode, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);
+// the 256-wide single-gradient kernels by the number of 32-column blocks that can hold valid head-dim columns (5..8)
+template <typename T, int DVB>
+hipError_t launch_bwd_wide(const BArgs& a, int mode, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);
 // dK and dV in one launch (tfa_bwd_kv_kernel.h): grid = B * Hk * ceil(Nk / 128)
 template <typename T, int D>
 hipError_t launch_bwd_kv(const BArgs& a, int grid, bool causal, bool f32out, hipStream_t stream, bool dry);   // a.ws != nullptr: also writes dS
