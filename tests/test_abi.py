@@ -152,21 +152,21 @@ def test_suggested_split_count():
     assert sug(B=8, H=32, Hk=32, Nq=1, Nk=16384) == 1            # 256 workgroups already
     assert sug(B=1, H=32, Hk=32, Nq=1, Nk=2048) == 1             # short cache: the merge is not worth it
     assert sug(B=4, H=32, Hk=32, Nq=4096, Nk=4096) == 1
-    assert sug(B=1, H=8, Hk=8, Nq=1, Nk=16384, D=256) == 1       # D > 128 splits one launch per chunk: never suggested
+    assert sug(B=1, H=8, Hk=8, Nq=1, Nk=16384, D=256) == 4       # D > 128 splits one launch per chunk over four side streams: four chunks at most
 
 
-def test_split_suggestion_respects_the_one_descriptor_limit():
-    # a decode call over a long strided KV cache whose (b,h) slice spans more than 2 GiB: tfa_fwd plans it (windowed il kernel),
-    # tfa_fwd_splitkv could not (one descriptor per slice) -> the suggestion must be 1, so that every auto-split caller stays
-    # on tfa_fwd
+def test_split_suggestion_for_slices_beyond_one_descriptor():
+    # a decode call over a long strided KV cache whose (b,h) slice spans more than 2 GiB: tfa_fwd plans it (windowed il kernel) and
+    # tfa_fwd_splitkv takes its one-launch-per-chunk route through the same kernel (round 2 refused; ADVICE r02, medium: the
+    # suggestion must never point at a call that fails) -> a small chunk count, as for head dims above 128
     L = _lib.lib()
     p = _params(B=1, H=8, Hk=1, Nq=1, Nk=300000, D=128)
     a = p.k_stride; a[0], a[1], a[2] = 300000 * 4096, 128, 4096
     a = p.v_stride; a[0], a[1], a[2] = 300000 * 4096, 128, 4096
     assert plan(p)[0] == 0
-    assert L.tfa_fwd_suggest_splits(C.byref(p)) == 1
-    small = _params(B=1, H=8, Hk=1, Nq=1, Nk=300000, D=128)        # the same problem with a dense cache does split
-    assert L.tfa_fwd_suggest_splits(C.byref(small)) > 1
+    assert L.tfa_fwd_suggest_splits(C.byref(p)) == 4
+    small = _params(B=1, H=8, Hk=1, Nq=1, Nk=300000, D=128)        # the same problem with a dense cache: all chunks in one launch
+    assert L.tfa_fwd_suggest_splits(C.byref(small)) > 4
 
 
 def test_gqa_packing_is_an_optimisation_never_a_requirement():

@@ -114,3 +114,40 @@ def test_partial_forward_semantics(oracle, dev):
     fin = torch.isfinite(lref)
     assert (lse.cpu()[fin] - lref[fin]).abs().max().item() <= 1e-4
     assert (o32.cpu() - ref).abs().max().item() <= 1e-2
+
+
+def test_chunk_route_side_streams_and_graph_capture(oracle, dev):
+    """Head dims above 128 (and slices of 2 GiB and more) run tfa_fwd_splitkv as one launch per key chunk, forked over the calling
+    thread's side streams and joined before the merge.  (1) Same bits as the chunks launched in line (debug flag 16384);
+    (2) the fork / join is legal inside a stream capture: the call is captured into a HIP graph and replayed on new data."""
+    from tiny_flash_attention_amd import _lib, ops
+
+    B, H, Hk, Nq, Nk, D = 1, 8, 4, 3, 6000, 256
+    g = torch.Generator(device=dev).manual_seed(77)
+    mk = lambda n, h: torch.empty((B, h, n, D), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(torch.bfloat16)
+    q, k, v = mk(Nq, H), mk(Nk, Hk), mk(Nk, Hk)
+    sc = 1.0 / math.sqrt(D)
+    o1, l1 = ops.flash_attn_fwd_splitkv(q, k, v, True, sc, splits=4)
+    _lib.debug_set_flags(16384)
+    try:
+        o2, l2 = ops.flash_attn_fwd_splitkv(q, k, v, True, sc, splits=4)
+    finally:
+        _lib.debug_set_flags(0)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    full, lse_full = ops.flash_attn_fwd(q, k, v, True, sc)
+    assert (o1.float() - full.float()).abs().max().item() <= 4e-3 and (l1 - lse_full).abs().max().item() <= 1e-4
+    # graph capture and replay on fresh inputs
+    sq, sk, sv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.flash_attn_fwd_splitkv(sq, sk, sv, True, sc, splits=4)      # warm-up outside the capture (lazy stream / attribute set-up)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        go, gl = ops.flash_attn_fwd_splitkv(sq, sk, sv, True, sc, splits=4)
+    sq.copy_(q); sk.copy_(k); sv.copy_(v)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(go, o1) and torch.equal(gl, l1)

@@ -284,6 +284,40 @@ int tfa_fwd_plan(const tfa_fwd_params* p, int* grid, int* block, int* lds_bytes)
   return TFA_OK;
 }
 
+// ---- side streams for the one-launch-per-chunk route of tfa_fwd_splitkv ----------------------------------------------------
+// The chunk launches of one call are independent; on ONE stream they run one after the other and a decode-like problem (few
+// workgroups per launch) fills the chip no better than tfa_fwd.  They are therefore forked over a few side streams and joined
+// back into the caller's stream before the merge (event fork / join: legal inside a stream capture too).  The streams and events
+// belong to the calling thread and the current device; they are created on first use and live as long as the thread.
+constexpr int kSideStreams = 4;
+struct SideStreams {
+  int device = -1;
+  hipStream_t s[kSideStreams] = {};
+  hipEvent_t fork = nullptr, join[kSideStreams] = {};
+  bool ok = false;
+};
+SideStreams* side_streams() {
+  thread_local SideStreams pools[8];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  SideStreams* sp = nullptr;
+  for (auto& q : pools)
+    if (q.device == dev) { sp = &q; break; }
+  if (!sp)
+    for (auto& q : pools)
+      if (q.device < 0) { sp = &q; break; }
+  if (!sp) return nullptr;                                   // (more than eight devices driven by one thread: run the chunks in line)
+  if (sp->device == dev) return sp->ok ? sp : nullptr;
+  sp->device = dev;
+  bool ok = hipEventCreateWithFlags(&sp->fork, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < kSideStreams && ok; ++i)
+    ok = hipStreamCreateWithFlags(&sp->s[i], hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&sp->join[i], hipEventDisableTiming) == hipSuccess;
+  sp->ok = ok;
+  if (!ok) (void)hipGetLastError();
+  return ok ? sp : nullptr;
+}
+
 // ---- split-KV in one launch ------------------------------------------------------------------------------------------
 static int splitkv_geometry(const tfa_fwd_params* p, int splits, int* nsplit, int* chunk) {
   if (!p || splits < 1) return TFA_ERR_SHAPE;
@@ -327,7 +361,17 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
     // caches) take the same route: the LDS-DMA kernel below addresses a slice through ONE descriptor, tfa_fwd's il kernels through
     // windows.  (Debug flag 8192 forces this route: tests compare it with the one-launch form.)
     const int64_t rs_k = p->k_stride[2], rs_v = p->v_stride[2];
-    for (int c = 0; c < ns; ++c) {
+    hipStream_t caller = reinterpret_cast<hipStream_t>(stream);
+    // chunks that leave the chip mostly idle run side by side on the thread's side streams (debug flag 16384: in line)
+    const long long blocks = (long long)p->B * p->H * ((p->Nq + 127) / 128);
+    SideStreams* ss = (ns >= 2 && blocks * 2 <= num_cus() && !(g_dbg_flags & 16384)) ? side_streams() : nullptr;
+    if (ss) {
+      if (hipEventRecord(ss->fork, caller) != hipSuccess) ss = nullptr;
+      for (int i = 0; ss && i < kSideStreams; ++i)
+        if (hipStreamWaitEvent(ss->s[i], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
+    }
+    int st_chunks = TFA_OK;
+    for (int c = 0; c < ns && st_chunks == TFA_OK; ++c) {
       tfa_fwd_params qc = q;
       const int64_t k0 = (int64_t)c * ch;
       qc.k = reinterpret_cast<const char*>(p->k) + k0 * rs_k * 2;
@@ -337,9 +381,15 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
       qc.nk_total = p->Nk;
       qc.out = ws_o + (long long)c * rows * p->D;
       qc.lse = ws_l + (long long)c * rows;
-      st = run(&qc, stream, nullptr, false);
-      if (st != TFA_OK) return st;
+      st_chunks = run(&qc, ss ? (void*)ss->s[c % kSideStreams] : stream, nullptr, false);
     }
+    if (ss) {                                              // join — also after a failed launch: the caller's stream must not lose the fork
+      for (int i = 0; i < kSideStreams; ++i) {
+        if (hipEventRecord(ss->join[i], ss->s[i]) != hipSuccess || hipStreamWaitEvent(caller, ss->join[i], 0) != hipSuccess)
+          return st_chunks != TFA_OK ? st_chunks : (int)hipGetLastError();
+      }
+    }
+    if (st_chunks != TFA_OK) return st_chunks;
     return tfa_merge(ws_o, ws_l, ns, rows, p->D, rows * p->D, rows, p->out, p->out_dtype, p->lse, stream);
   }
   {
@@ -371,12 +421,9 @@ int tfa_fwd_suggest_splits(const tfa_fwd_params* p_in) {
   if (p_in->flags & TFA_FWD_EXACT_MAX) return 1;          // (the merge of partial passes moves the rounding points as well)
   tfa_fwd_params packed;
   const tfa_fwd_params* p = pack_gqa_rows(p_in, &packed) ? &packed : p_in;
-  // (head dims above 128: tfa_fwd_splitkv works — one launch per chunk — but launches on one stream run one after the other, so it
-  //  fills the chip no better than tfa_fwd: never suggested)
-  if (p->D > 128 || p->kv_offset != 0 || p->nk_total != 0 || p->B <= 0 || p->H <= 0 || p->Nq <= 0) return 1;
-  // tfa_fwd_splitkv runs the one-descriptor-per-slice LDS-DMA kernel: a K/V cache whose (b,h) slice spans 2 GiB or more (long
-  // strided caches) stays on tfa_fwd, whose il kernels address it through windows
-  if (!one_descriptor(p)) return 1;
+  // (head dims above 128 and (b,h) slices of 2 GiB and more take tfa_fwd_splitkv's one-launch-per-chunk route, the launches spread
+  //  over side streams: the same suggestion applies)
+  if (p->kv_offset != 0 || p->nk_total != 0 || p->B <= 0 || p->H <= 0 || p->Nq <= 0) return 1;
   const long long blocks = (long long)p->B * p->H * ((p->Nq + 127) / 128);
   const int cus = num_cus();
   if (blocks * 4 > cus || p->Nk < 4096) return 1;
@@ -384,6 +431,10 @@ int tfa_fwd_suggest_splits(const tfa_fwd_params* p_in) {
   long long s = cus / blocks;
   if (s > p->Nk / 1024) s = p->Nk / 1024;
   if (s > 32) s = 32;
+  // one launch per chunk (head dims above 128, slices of 2 GiB and more): every chunk costs a launch on the host and the four side
+  // streams overlap about two launches' worth — measured 1.4-1.8x over one pass at four chunks, less at eight or sixteen
+  // (tools/bench_decode_wide.py, profiles/r03_decode_wide.txt)
+  if ((p->D > 128 || !one_descriptor(p)) && s > 4) s = 4;
   return s >= 2 ? (int)s : 1;
 }
 

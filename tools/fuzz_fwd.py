@@ -38,7 +38,7 @@ for it in range(a.n):
     if a.big and kind < 0.35:
         Nq = Nk = rng.choice([1024, 2048, 4096, 8192]) + rng.choice([0, 0, 1, -1, 17, -37])
     if a.decode:
-        D = rng.choice([64, 128, 96, 32])
+        D = rng.choice([64, 128, 96, 32, 256, 192])          # (above 128: one launch per chunk over the side streams)
         B, Hk = rng.choice([1, 1, 2]), rng.choice([1, 2, 4, 8]); H = Hk * rng.choice([1, 2, 4])
         Nq, Nk = rng.choice([1, 1, 2, 7, 16, 33, 128, 200]), rng.randint(4096, 40000)
         layout = "bhnd"
