@@ -172,8 +172,8 @@ int tfa_merge(const float* o_parts, const float* lse_parts, int nparts, int64_t 
 
 /* Split-KV on one GPU in ONE launch (decode-like shapes: few query rows, long K/V, too few workgroups to fill the
  * chip): the key sequence is cut into `splits` chunks (multiples of 64 keys), the grid carries one copy of the work per
- * chunk (LDS-DMA kernel), partials go to `workspace`, tfa_merge writes *p's out (contiguous (B,H,Nq,D)) and lse.
- * Head dims above 128 and (b,h) slices of 2 GiB and more: one launch of tfa_fwd's kernel per chunk instead; when such a launch leaves
+ * chunk (LDS-DMA kernel, 64 / 128 / 256 wide), partials go to `workspace`, tfa_merge writes *p's out (contiguous (B,H,Nq,D)) and lse.
+ * (b,h) slices of 2 GiB and more: one launch of tfa_fwd's windowed kernel per chunk instead; when such a launch leaves
  * the chip mostly idle the launches are forked over four side streams owned by the calling thread and joined into `stream` before the
  * merge (event fork / join: legal inside a stream capture).  Everything the call enqueues is ordered before later work on `stream`.
  * workspace: tfa_fwd_splitkv_workspace(p, splits) floats (16-byte aligned); negative return = TFA_ERR_*. */
@@ -182,8 +182,8 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
 /* The split count a host that can provide a workspace should use for *p: 1 = call tfa_fwd (the grid fills the chip, or the
  * keys are too few to be worth a merge), >= 2 = call tfa_fwd_splitkv with that many chunks (decode-like shapes: B*H*ceil(Nq/128)
  * workgroups on a quarter of the CUs or fewer, at least 4096 keys, causal only when Nq <= Nk/4; measured 3-9x on B1 H32 Nq1
- * Nk16k..64k, B1 H8 Nq16 Nk32k, 1.7-2x on short non-causal / chunked-prefill problems with one to four heads; at most 4 for the
- * one-launch-per-chunk route: 1.4-1.8x).
+ * Nk16k..64k, B1 H8 Nq16 Nk32k, 1.7-2x on short non-causal / chunked-prefill problems with one to four heads; head dims above 128:
+ * 4-11x, K/V at 3.6-5.5 TB/s; at most 4 for the one-launch-per-chunk route of slices beyond 2 GiB: 1.4-1.8x).
  * The reference-named bindings (attention_cutlass / attention_cuda / _kernels and their Python mirrors) follow it. */
 int tfa_fwd_suggest_splits(const tfa_fwd_params* p);
 

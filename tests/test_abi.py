@@ -152,13 +152,13 @@ def test_suggested_split_count():
     assert sug(B=8, H=32, Hk=32, Nq=1, Nk=16384) == 1            # 256 workgroups already
     assert sug(B=1, H=32, Hk=32, Nq=1, Nk=2048) == 1             # short cache: the merge is not worth it
     assert sug(B=4, H=32, Hk=32, Nq=4096, Nk=4096) == 1
-    assert sug(B=1, H=8, Hk=8, Nq=1, Nk=16384, D=256) == 4       # D > 128 splits one launch per chunk over four side streams: four chunks at most
+    assert sug(B=1, H=8, Hk=8, Nq=1, Nk=16384, D=256) == 16      # head dims above 128: the same LDS-DMA kernel, 256 wide
 
 
 def test_split_suggestion_for_slices_beyond_one_descriptor():
     # a decode call over a long strided KV cache whose (b,h) slice spans more than 2 GiB: tfa_fwd plans it (windowed il kernel) and
     # tfa_fwd_splitkv takes its one-launch-per-chunk route through the same kernel (round 2 refused; ADVICE r02, medium: the
-    # suggestion must never point at a call that fails) -> a small chunk count, as for head dims above 128
+    # suggestion must never point at a call that fails) -> a small chunk count (four side streams carry the launches)
     L = _lib.lib()
     p = _params(B=1, H=8, Hk=1, Nq=1, Nk=300000, D=128)
     a = p.k_stride; a[0], a[1], a[2] = 300000 * 4096, 128, 4096

@@ -11,6 +11,11 @@
 #include "tfa.h"
 #include "tfa_launch.h"
 
+namespace tfa {
+template <> hipError_t launch_splitkv_wide<__bf16>(const KArgs&, bool, hipStream_t, LaunchGeom*, bool);
+template <> hipError_t launch_splitkv_wide<_Float16>(const KArgs&, bool, hipStream_t, LaunchGeom*, bool);
+}  // namespace tfa
+
 namespace {
 
 // Debug knobs (tfa_set_variant, tfa_debug_set_trace) are PER THREAD: a thread that forces a variant or a trace buffer
@@ -86,7 +91,7 @@ bool slice_bytes(int64_t n, int64_t row_stride, int d, int esize, bool windowed,
   return true;
 }
 
-int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant, int row_mod = 0) {
+int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant, int row_mod = 0, bool wide_split = false) {
   if (!p) return TFA_ERR_NULL;
   if (!p->q || !p->k || !p->v || !p->out) return TFA_ERR_NULL;
   if (p->dtype != TFA_F16 && p->dtype != TFA_BF16) return TFA_ERR_DTYPE;
@@ -100,7 +105,8 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant, int row_mod = 
   const bool ablate = (variant >= 100 && variant < 100 + 512) || (variant >= 700 && variant < 716) || (variant >= 1000 && variant < 2256) || (variant >= 3000 && variant < 3256);   // timing-only ablations (debug)
   if (!ablate && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
   if (p->D != 64 && p->D != 128 && (ablate || !tfa::supports_padded_d(variant))) return TFA_ERR_HEAD_DIM;   // (A/B arms: 64 / 128 only)
-  if ((p->D > 128) != (variant == tfa::kX4D256Variant)) return TFA_ERR_HEAD_DIM;
+  // (wide_split: tfa_fwd_splitkv's partial pass — the LDS-DMA kernel exists 256 wide for that purpose only)
+  if (p->D > 128 ? !(variant == tfa::kX4D256Variant || (wide_split && variant == tfa::kSplitVariant)) : variant == tfa::kX4D256Variant) return TFA_ERR_HEAD_DIM;
   const int esz = 2, osz = (p->out_dtype == TFA_F32) ? 4 : 2;
   const int64_t* st[4] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride};
   for (int t = 0; t < 4; ++t) {
@@ -354,12 +360,11 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   q.lse = ws_l;
   q.out_dtype = TFA_F32;
   q.o_stride[0] = (int64_t)p->H * p->Nq * p->D; q.o_stride[1] = (int64_t)p->Nq * p->D; q.o_stride[2] = p->D;
-  if (p->D > 128 || !one_descriptor(p) || (g_dbg_flags & 8192)) {
-    // Head dims 136..256: the one kernel that wide (x4-d256) has no chunk dimension in its grid, so the partial passes are `ns`
-    // launches of tfa_fwd over key chunks (kv_offset / nk_total: the causal mask stays against global key positions) — one
-    // launch per chunk instead of one in all, same partials, same merge.  (b,h) slices of 2 GiB and more (long strided K/V
-    // caches) take the same route: the LDS-DMA kernel below addresses a slice through ONE descriptor, tfa_fwd's il kernels through
-    // windows.  (Debug flag 8192 forces this route: tests compare it with the one-launch form.)
+  if (!one_descriptor(p) || (g_dbg_flags & 8192)) {
+    // (b,h) slices of 2 GiB and more (long strided K/V caches): the LDS-DMA kernel below addresses a slice through ONE descriptor,
+    // tfa_fwd's kernels through windows — the partial passes are `ns` launches of tfa_fwd over key chunks (kv_offset / nk_total:
+    // the causal mask stays against global key positions), one launch per chunk instead of one in all, same partials, same
+    // merge.  (Debug flag 8192 forces this route: tests compare it with the one-launch form.)
     const int64_t rs_k = p->k_stride[2], rs_v = p->v_stride[2];
     hipStream_t caller = reinterpret_cast<hipStream_t>(stream);
     // chunks that leave the chip mostly idle run side by side on the thread's side streams (debug flag 16384: in line)
@@ -398,7 +403,7 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   }
   const int variant = tfa::kSplitVariant;                 // the LDS-DMA kernel carries the chunk dimension in its grid
   tfa::KArgs a;
-  st = validate(&q, &a, variant);
+  st = validate(&q, &a, variant, 0, true);
   if (st != TFA_OK) return st;
   a.nsplit = ns;
   a.chunk = ch;
@@ -408,7 +413,9 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipError_t e;
   const bool causal = q.is_causal != 0;                   // (the packed one-row problem is non-causal)
-  if (p->dtype == TFA_BF16)
+  if (p->D > 128)                                          // head dims 136..256: the same kernel 256 wide (one wave per SIMD, hand-owned accumulators)
+    e = (p->dtype == TFA_BF16) ? tfa::launch_splitkv_wide<__bf16>(a, causal, s, nullptr, false) : tfa::launch_splitkv_wide<_Float16>(a, causal, s, nullptr, false);
+  else if (p->dtype == TFA_BF16)
     e = (p->D > 64) ? tfa::launch_fwd<__bf16, 128>(a, causal, true, variant, s, nullptr, false) : tfa::launch_fwd<__bf16, 64>(a, causal, true, variant, s, nullptr, false);
   else
     e = (p->D > 64) ? tfa::launch_fwd<_Float16, 128>(a, causal, true, variant, s, nullptr, false) : tfa::launch_fwd<_Float16, 64>(a, causal, true, variant, s, nullptr, false);
@@ -421,8 +428,8 @@ int tfa_fwd_suggest_splits(const tfa_fwd_params* p_in) {
   if (p_in->flags & TFA_FWD_EXACT_MAX) return 1;          // (the merge of partial passes moves the rounding points as well)
   tfa_fwd_params packed;
   const tfa_fwd_params* p = pack_gqa_rows(p_in, &packed) ? &packed : p_in;
-  // (head dims above 128 and (b,h) slices of 2 GiB and more take tfa_fwd_splitkv's one-launch-per-chunk route, the launches spread
-  //  over side streams: the same suggestion applies)
+  // ((b,h) slices of 2 GiB and more take tfa_fwd_splitkv's one-launch-per-chunk route, the launches spread over side streams: a
+  //  small chunk count, below)
   if (p->kv_offset != 0 || p->nk_total != 0 || p->B <= 0 || p->H <= 0 || p->Nq <= 0) return 1;
   const long long blocks = (long long)p->B * p->H * ((p->Nq + 127) / 128);
   const int cus = num_cus();
@@ -431,10 +438,10 @@ int tfa_fwd_suggest_splits(const tfa_fwd_params* p_in) {
   long long s = cus / blocks;
   if (s > p->Nk / 1024) s = p->Nk / 1024;
   if (s > 32) s = 32;
-  // one launch per chunk (head dims above 128, slices of 2 GiB and more): every chunk costs a launch on the host and the four side
+  // one launch per chunk (slices of 2 GiB and more): every chunk costs a launch on the host and the four side
   // streams overlap about two launches' worth — measured 1.4-1.8x over one pass at four chunks, less at eight or sixteen
   // (tools/bench_decode_wide.py, profiles/r03_decode_wide.txt)
-  if ((p->D > 128 || !one_descriptor(p)) && s > 4) s = 4;
+  if (!one_descriptor(p) && s > 4) s = 4;
   return s >= 2 ? (int)s : 1;
 }
 

@@ -21,7 +21,7 @@
 // the issue-interleaving of tfa_fwd_kernel_il.h is the next step for this kernel.
 #pragma once
 #include "tfa_fwd_kernel_dma.h"
-#include "tfa_bwd_acc_regs.h"
+#include "tfa_acc_regs.h"
 
 namespace tfa {
 
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
     delta_lane = p.delta[si];
   }
 
-  constexpr bool OWN_ACC = NW == 4;                  // head dims above 128: the accumulators are the hand-owned a[0:127] (tfa_bwd_acc_regs.h)
+  constexpr bool OWN_ACC = NW == 4;                  // head dims above 128: the accumulators are the hand-owned a[0:127] (tfa_acc_regs.h)
   f32x16 acc[OWN_ACC ? 1 : DT];
   if (OWN_ACC) g_zero();
   else {

@@ -14,6 +14,7 @@
 // Out-of-range rows still read as zeros (buffer descriptor bounds check), so ragged N is unchanged.
 #pragma once
 #include "tfa_fwd_kernel.h"
+#include "tfa_acc_regs.h"
 
 namespace tfa {
 
@@ -95,7 +96,11 @@ constexpr int VF_PRIO = 1024;   // s_setprio(1) around the MFMA clusters (experi
 // requested BEFORE the current block's epilogue, so its prologue latency hides behind the O stores.
 // With G = number of items the same code degenerates to one item per workgroup.
 template <typename T, int D, int NW, bool CAUSAL, bool F32OUT, int VF, int AB = 0>
-__global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
+// D = 256 (WIDE): the partial pass of tfa_fwd_splitkv at head dims above 128 — a K/V streaming kernel for decode-like shapes.  One wave
+// per SIMD with the whole register file; O lives in the hand-owned AccVGPRs a[0:127] and Q is read from AccVGPRs (tfa_acc_regs.h:
+// left to hipcc's own AccVGPR plan this instantiation spills 252 registers and streams 8-9 GB/s per workgroup); LDS fragments are
+// read a group ahead of the asm MFMAs.
+__global__ __launch_bounds__(NW * 64, D > 128 ? 1 : 2) void fwd_kernel_dma(const KArgs p) {
   using E = Elem<T>;
   using X8 = typename E::x8;
   constexpr int BM = NW * 32;
@@ -109,7 +114,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
   constexpr int DS = D / 16;
   constexpr int DT = D / 32;
   constexpr bool PAIR = CAUSAL && (VF & VF_PAIR);
+  constexpr bool WIDE = D > 128;
   static_assert(PPW >= 1 && PPW * NW == PIECES, "tile does not split into whole DMA pieces per wave");
+  static_assert(!WIDE || (NW == 4 && AB == 0), "the 256-wide form: four waves, no ablations");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const kl = smem;                           // K buffers 0..2
@@ -241,18 +248,23 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
     const int wave_row0 = cur.mb * BM + wave * 32;
     const int my_row = wave_row0 + qi;
 
-    f32x16 oacc[DT];
+    f32x16 oacc[WIDE ? 1 : DT];
+    if constexpr (WIDE) g_zero();
+    else {
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+      for (int d = 0; d < (WIDE ? 1 : DT); ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    }
     float m_run = -1e30f;
     float l_run = 0.f;
 
     // tiles 0/1 and Q have been requested (prologue, or beside the previous block's epilogue)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));
+    for (int s = 0; s < DS; ++s) {
+      if (WIDE) asm volatile("" : "+a"(qf[s])); else asm volatile("" : "+v"(qf[s]));
+    }
     asm volatile("s_barrier" ::: "memory");
     if (p.trace && first) t_pro = __builtin_amdgcn_s_memtime();
 
@@ -273,7 +285,32 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
-        {
+        if constexpr (WIDE) {
+          // k-steps in groups of four, the fragments of a group read one group ahead of the asm MFMAs that use them
+          constexpr int GS = 4, NG = DS / GS;
+          X8 kq[2][GS][2];
+          auto rdk = [&](int gq, int buf) {
+#pragma unroll
+            for (int i = 0; i < GS; ++i)
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+                kq[buf][i][t] = __builtin_bit_cast(X8, lds_read_b128(kb, k_rd_base + t * 32 * (D * 2) + (((2 * (gq * GS + i) + hi) ^ k_rd_swz) << 4)));
+          };
+          rdk(0, 0);
+#pragma unroll
+          for (int gq = 0; gq < NG; ++gq) {
+            if (gq + 1 < NG) rdk(gq + 1, (gq + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < GS; ++i)
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                if (gq == 0 && i == 0) E::template mfma_bacc<true>(kq[0][0][t], qf[0], sacc[t]);      // (sacc was just zeroed by VALU moves)
+                else E::template mfma_bacc<false>(kq[gq & 1][i][t], qf[gq * GS + i], sacc[t]);
+              }
+          }
+          mfma_drain(sacc[0]);
+          asm volatile("" : "+v"(sacc[1]));
+        } else {
           X8 kf[DS][2];
 #pragma unroll
           for (int s = 0; s < DS; ++s)
@@ -294,9 +331,19 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
           if (VF & VF_PRIO) __builtin_amdgcn_s_setprio(0);
         }
 
-        s16x8 vfr[DT][4];
+        auto rdv = [&](int s, int d) -> s16x8 {
+          const char* a = vb + v_rd_base + (s * 2 * DT << 9) + (d << 9);
+          const s16x4 lo = lds_read_tr16_b64(a), hh = lds_read_tr16_b64(a + 256);
+          return __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        s16x8 vq[WIDE ? 2 : 1][WIDE ? DT : 1];                // WIDE: the DT fragments of one 16-key slot, read one slot ahead
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+          for (int d = 0; d < DT; ++d) vq[0][d] = rdv(0, d);
+        }
+        s16x8 vfr[WIDE ? 1 : DT][WIDE ? 1 : 4];
+#pragma unroll
+        for (int s = 0; s < (WIDE ? 0 : 4); ++s)
 #pragma unroll
           for (int d = 0; d < DT; ++d) {
             const char* a = vb + v_rd_base + (s * 2 * DT << 9) + (d << 9);
@@ -338,10 +385,13 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
         if (__any(changed)) {
           const float alpha = fast_exp2((m_run - m_new) * sc);
           l_run *= alpha;
+          if constexpr (WIDE) g_scale(alpha);
+          else {
 #pragma unroll
-          for (int d = 0; d < DT; ++d)
+            for (int d = 0; d < (WIDE ? 1 : DT); ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+              for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+          }
         }
         m_run = m_new;
         const float msc = m_new * sc;
@@ -360,13 +410,28 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
         l_run += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
 
         if (VF & VF_PRIO) __builtin_amdgcn_s_setprio(1);
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+          for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) {
 #pragma unroll
-          for (int d = 0; d < DT; ++d) {
-            if (AB & AB_NOPV) asm volatile("" ::"v"(vfr[d][s]), "v"(pk[s]));
-            else oacc[d] = E::mfma(__builtin_bit_cast(X8, vfr[d][s]), pk[s], oacc[d]);
+              for (int d = 0; d < DT; ++d) vq[(s + 1) & 1][d] = rdv(s + 1, d);
+            }
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+              if (d == 0) g_mfma_d<T, true>(d, __builtin_bit_cast(X8, vq[s & 1][d]), pk[s]);
+              else g_mfma_d<T, false>(d, __builtin_bit_cast(X8, vq[s & 1][d]), pk[s]);
+            }
           }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int d = 0; d < (WIDE ? 1 : DT); ++d) {
+              if (AB & AB_NOPV) asm volatile("" ::"v"(vfr[d][s]), "v"(pk[s]));
+              else oacc[d] = E::mfma(__builtin_bit_cast(X8, vfr[d][s]), pk[s], oacc[d]);
+            }
+        }
         if (VF & VF_PRIO) __builtin_amdgcn_s_setprio(0);
       }
 
@@ -419,6 +484,12 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
 
     // ---- epilogue of the block just finished ------------------------------------------------------
     const int ob = cur_bh / p.H, oh = cur_bh - ob * p.H;
+    float og[WIDE ? DT : 1][16];                           // WIDE: O read out of the hand-owned AccVGPRs
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d) g_read_d(d, og[d]);
+    }
+    auto ov = [&](int d, int i) -> float { return WIDE ? og[WIDE ? d : 0][i] : oacc[WIDE ? 0 : d][i]; };
     const float l_tot = pair_sum(l_run);
     const bool empty = !(l_tot > 0.f);
     const float inv = empty ? 1.f : 1.f / l_tot;
@@ -434,7 +505,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
       for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          f32x4 v4 = {oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv};
+          f32x4 v4 = {ov(d, 4 * g + 0) * inv, ov(d, 4 * g + 1) * inv, ov(d, 4 * g + 2) * inv, ov(d, 4 * g + 3) * inv};
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), o_rs, d * 32 + g * 8 + hi * 4 < p.dv ? ooff + (d * 32 + g * 8) * 4 : (int)TFA_OOB, 0, 0);
         }
     } else if (LDS_EPI) {
@@ -452,7 +523,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
       for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          t4 v4 = {(T)(oacc[d][4 * g + 0] * inv), (T)(oacc[d][4 * g + 1] * inv), (T)(oacc[d][4 * g + 2] * inv), (T)(oacc[d][4 * g + 3] * inv)};
+          t4 v4 = {(T)(ov(d, 4 * g + 0) * inv), (T)(ov(d, 4 * g + 1) * inv), (T)(ov(d, 4 * g + 2) * inv), (T)(ov(d, 4 * g + 3) * inv)};
           const int c = d * 4 + g;
           *reinterpret_cast<u32x2*>(ow + qi * (D * 2) + ((c ^ osw) << 4) + hi * 8) = __builtin_bit_cast(u32x2, v4);
         }
@@ -480,7 +551,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel_dma(const KArgs p) {
       for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          t4 v4 = {(T)(oacc[d][4 * g + 0] * inv), (T)(oacc[d][4 * g + 1] * inv), (T)(oacc[d][4 * g + 2] * inv), (T)(oacc[d][4 * g + 3] * inv)};
+          t4 v4 = {(T)(ov(d, 4 * g + 0) * inv), (T)(ov(d, 4 * g + 1) * inv), (T)(ov(d, 4 * g + 2) * inv), (T)(ov(d, 4 * g + 3) * inv)};
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), o_rs, d * 32 + g * 8 + hi * 4 < p.dv ? ooff + (d * 32 + g * 8) * 2 : (int)TFA_OOB, 0, 0);
         }
     }

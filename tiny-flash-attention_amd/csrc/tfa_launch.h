@@ -118,6 +118,10 @@ static inline hipError_t launch_common(Kern kern, std::atomic<unsigned long long
   return hipGetLastError();
 }
 
+// The LDS-DMA kernel 256 wide, fp32 partial output: tfa_fwd_splitkv's one-launch form for head dims above 128 (tfa_dma_inst_<dtype>_256.hip)
+template <typename T>
+hipError_t launch_splitkv_wide(const KArgs& a, bool causal, hipStream_t stream, LaunchGeom* geom, bool dry);
+
 // The x4 kernel: one translation unit per (dtype, width, causal, output type) — tfa_x4_inst_<dtype>_<D>_c<0|1>_o<16|32>.hip —
 // each specialising launch_x4_piece; ablate != 0 selects a timing-only ablation (builds with -DTFA_X4_ABLATE).
 template <typename T, int D, bool CAUSAL, bool F32OUT>

@@ -1,5 +1,6 @@
-"""Decode-like shapes at head dims above 128: tfa_fwd (one pass) vs tfa_fwd_splitkv (one launch per key chunk) with the chunk launches
-in line on the caller's stream (debug flag 16384) and spread over the side streams.  Wall time per call over 50 back-to-back calls
+"""Decode-like shapes at head dims above 128: tfa_fwd (one pass) vs tfa_fwd_splitkv — its one-launch form (the LDS-DMA kernel 256 wide,
+chunk index in the grid) and, forced by debug flag 8192, its one-launch-per-chunk route with the chunk launches in line on the
+caller's stream (flag 16384) or spread over the side streams.  Wall time per call over 50 back-to-back calls
 (host launch costs included).  usage: python tools/bench_decode_wide.py"""
 import math, os, sys, time
 import torch
@@ -23,15 +24,18 @@ for (B, H, Hk, Nq, Nk, D) in ((1, 8, 8, 1, 16384, 256), (1, 16, 16, 1, 65536, 25
     ref, _ = ops.flash_attn_fwd(q, k, v, True, sc)
     t1 = wall(lambda: ops.flash_attn_fwd(q, k, v, True, sc))
     res = []
-    for splits in (4, 8, 16):
+    for splits in (8, 16, 32):
         o, _ = ops.flash_attn_fwd_splitkv(q, k, v, True, sc, splits=splits)
         err = (o.float() - ref.float()).abs().max().item()
-        _lib.debug_set_flags(16384)
-        try:
-            ta = wall(lambda: ops.flash_attn_fwd_splitkv(q, k, v, True, sc, splits=splits))
-        finally:
-            _lib.debug_set_flags(0)
-        tb = wall(lambda: ops.flash_attn_fwd_splitkv(q, k, v, True, sc, splits=splits))
-        res.append(f"{splits} chunks: in line {ta:7.1f} us, side streams {tb:7.1f} us (max|d| {err:.1e})")
+        t0 = wall(lambda: ops.flash_attn_fwd_splitkv(q, k, v, True, sc, splits=splits))
+        res.append(f"{splits} chunks: one launch {t0:7.1f} us = {2 * B * Hk * Nk * D * 2 / t0 / 1e6:5.2f} TB/s (max|d| {err:.1e})")
+    _lib.debug_set_flags(8192 | 16384)
+    try:
+        ta = wall(lambda: ops.flash_attn_fwd_splitkv(q, k, v, True, sc, splits=4))
+        _lib.debug_set_flags(8192)
+        tb = wall(lambda: ops.flash_attn_fwd_splitkv(q, k, v, True, sc, splits=4))
+    finally:
+        _lib.debug_set_flags(0)
+    res.append(f"per-chunk launches (4 chunks) in line {ta:7.1f} us, over side streams {tb:7.1f} us")
     kv_gb = 2 * B * Hk * Nk * D * 2 / 1e9
     print(f"B{B} H{H} Hk{Hk} Nq{Nq} Nk{Nk} D{D}: one pass {t1:7.1f} us = {kv_gb / t1 * 1e6 / 1e3:5.2f} TB/s of K/V | " + " | ".join(res), flush=True)
