@@ -121,7 +121,10 @@ constexpr int X4AB_NOEXP = 1, X4AB_NODMA = 2, X4AB_NOBARRIER = 4, X4AB_NOMAX = 8
 
 // RB = 32-row blocks per wave: 2 at D <= 128 (256-row workgroups), 1 at D = 256 (128-row workgroups) — RB * D = 256 keeps O
 // (RB * D/32 * 16 = 128 registers) and Q (RB * D/16 * 4 = 64) in the same hand-owned AGPRs and a tile at 64 MFMAs per wave.
-template <typename T, int D, bool CAUSAL, bool F32OUT, int VF, int AB = 0, int RB = (D <= 128 ? 2 : 1)>
+// DVB (256-wide form only): 32-wide column blocks that can hold valid head-dim columns, ceil(head dim / 32) = 5..8.  The LDS tiles and
+// every address stay 256 wide (the columns beyond the head dim are the descriptors' zeros); K / Q fragments, V fragments, the MFMAs
+// and the O registers cover the valid blocks only (head dim 192: 48 of 64 MFMAs per tile).
+template <typename T, int D, bool CAUSAL, bool F32OUT, int VF, int AB = 0, int RB = (D <= 128 ? 2 : 1), int DVB = D / 32>
 __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   using M = X4<T>;
   using X8 = typename M::X8;
@@ -133,8 +136,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   constexpr int TILE_BYTES = BN * D * 2;
   constexpr int PIECES = TILE_BYTES / 1024;
   constexpr int PPW = PIECES / NW;                 // DMA pieces per wave per tensor per tile
-  constexpr int DS = D / 16;
-  constexpr int DT = D / 32;
+  static_assert(DVB == D / 32 || (D == 256 && RB == 1 && DVB >= 5 && DVB < 8), "DVB < D/32 exists for the 256-wide form only");
+  constexpr int DS = 2 * DVB;                      // k-slots of 16 columns that are multiplied
+  constexpr int DT = DVB;                          // 32-column tiles of O that exist
+  constexpr int DT_L = D / 32;                     // ... as the V tile's LDS layout counts them
   constexpr int NKF = 2 * DS;                      // K fragments per tile (key block kt = i & 1, k-slot ks = i >> 1)
   constexpr int NVF = 4 * DT;                      // V fragments per tile (key slot s = i / DT, d tile d = i % DT)
   constexpr int N1 = RB * NKF;                     // S MFMAs per tile
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     {
       const int o = pc * 1024 + lane * 16;
       const int sub = o >> 9, R = (o >> 6) & 7, pcs = (o >> 4) & 3;
-      const int dt = sub % DT, sh = sub / DT;
+      const int dt = sub % DT_L, sh = sub / DT_L;
       const int key = 16 * (sh >> 1) + 4 * (sh & 1) + 8 * (R >> 2) + (R & 3);
       v_src[i] = (dt * 4 + pcs) * 8 < p.dv ? key * (int)p.vs_n * 2 + ((dt * 4 + pcs) << 4) : (int)TFA_OOB;
     }
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   unsigned k_rd_addr = lds_base + qi * (D * 2) + ((hi ^ k_swz<D>(qi)) << 4);
   asm volatile("" : "+v"(k_rd_addr));
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-  const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
+  const int v_rd_base = (hi * DT_L << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
   const float sc = p.scale_log2;
   int nt_total = 0, n_slow = 0, n_trig = 0;
   const int dbg = p.dbg;                          // debug flags (tfa_debug_set_flags; 0 in normal use): see the uses below
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     return __builtin_bit_cast(X8, *reinterpret_cast<lds_u32x4*>(a));
   };
   auto v_frag = [&](const char* vb, int i) -> X8 {
-    const char* a = vb + v_rd_base + ((i / DT) * 2 * DT << 9) + ((i % DT) << 9);
+    const char* a = vb + v_rd_base + ((i / DT) * 2 * DT_L << 9) + ((i % DT) << 9);
     s16x4 lo = lds_read_tr16_b64(a);
     s16x4 hh = lds_read_tr16_b64(a + 256);
     return __builtin_bit_cast(X8, __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7));

@@ -134,6 +134,11 @@ hipError_t launch_x4_piece(const KArgs& a, int ablate, hipStream_t stream, Launc
 TFA_X4_PIECES(__bf16, 64) TFA_X4_PIECES(__bf16, 128) TFA_X4_PIECES(__bf16, 256)
 TFA_X4_PIECES(_Float16, 64) TFA_X4_PIECES(_Float16, 128) TFA_X4_PIECES(_Float16, 256)
 #undef TFA_X4_PIECES
+// the 256-wide x4 kernel with fewer than eight valid 32-column blocks (head dims 136..224): one unit per (dtype, causal, output type,
+// block count) — tfa_x4_inst_<dtype>_256_c<0|1>_o<16|32>_v<5|6|7>.hip
+template <typename T, bool CAUSAL, bool F32OUT, int DVB>
+hipError_t launch_x4_wide(const KArgs& a, hipStream_t stream, LaunchGeom* geom, bool dry);
+
 template <typename T, int D>
 static inline hipError_t launch_x4_unit(const KArgs& a, bool causal, bool f32out, int ablate, hipStream_t stream, LaunchGeom* geom, bool dry) {
   if (causal) return f32out ? launch_x4_piece<T, D, true, true>(a, ablate, stream, geom, dry) : launch_x4_piece<T, D, true, false>(a, ablate, stream, geom, dry);

@@ -1,0 +1,7 @@
+// one instantiation unit of the x4 kernel: dtype=bf16, 256 wide with 6 valid 32-column blocks (head dims 168..192), causal=1, 16-bit output
+#define TFA_T __bf16
+#define TFA_D 256
+#define TFA_CAUSAL true
+#define TFA_F32OUT false
+#define TFA_DVB 6
+#include "tfa_x4_inst.inc"

@@ -1,0 +1,7 @@
+// one instantiation unit of the x4 kernel: dtype=f16, 256 wide with 7 valid 32-column blocks (head dims 200..224), causal=0, fp32 output
+#define TFA_T _Float16
+#define TFA_D 256
+#define TFA_CAUSAL false
+#define TFA_F32OUT true
+#define TFA_DVB 7
+#include "tfa_x4_inst.inc"
