@@ -76,7 +76,8 @@ template <int D> static __device__ __forceinline__ int u_swz(int row) {
 // over the workgroup's resident rows, one over its gradient rows — and the 32-bit offsets are window-relative.  Its own instantiation
 // (a fresh descriptor per tile costs scalar work and wait states), launched only when a slice needs it; dQ mode only (the fused
 // dK/dV launch has its own).
-// DVB (256-wide kernels only): 32-wide column blocks that can hold valid head-dim columns — ceil(head dim / 32) = 5..8.  The LDS images
+// DVB: 32-wide column blocks that can hold valid head-dim columns — ceil(head dim / 32): 5..8 in the 256-wide kernels, 3 (head dims
+// up to 96) in the 128-wide dQ kernel, 1 (up to 32) in the 64-wide one.  The LDS images
 // and every address stay 256 wide (the columns beyond the head dim are the descriptors' zeros); the GEMM loops run over the valid
 // blocks only: at D = 160 / 192 / 224 that is 5/8, 6/8, 7/8 of the matrix work, fragment registers and LDS reads.
 template <typename T, int D, int MODE, bool CAUSAL, bool F32OUT, bool UNI = false, int NW = 8, bool BIG = false, int DVB = D / 32>
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
   constexpr int TILE_BYTES = BN * D * 2;
   constexpr int PIECES = TILE_BYTES / 1024;
   constexpr int PPW = PIECES / NW;
-  static_assert(DVB == D / 32 || (NW == 4 && DVB >= 1 && DVB < D / 32), "DVB < D/32 exists for the 256-wide one-wave-per-SIMD form only");
+  static_assert(DVB >= 1 && DVB <= D / 32, "valid 32-column blocks of a D-wide kernel");
   constexpr int DS = 2 * DVB;                      // k-steps of 16 columns (GEMM-I), resident fragments per tensor
   constexpr int DT = DVB;                          // 32-column tiles of the gradient (GEMM-II)
   constexpr int DT_L = D / 32;                     // ... as the LDS layouts count them

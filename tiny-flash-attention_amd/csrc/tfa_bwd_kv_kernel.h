@@ -28,7 +28,9 @@ namespace tfa {
 // never reads them.
 // BIG: (b,h) slices of 2 GiB and more — windowed descriptors as in bwd_kernel (one per streamed tile and image, one over the
 // workgroup's resident rows, one over its gradient rows); its own instantiation, without the workspace form.
-template <typename T, int D, bool CAUSAL, bool F32OUT, bool WS = false, int KG = 4, bool BIG = false>
+// DVB: 32-wide column blocks that can hold valid head-dim columns (tfa_bwd_kernel.h): 3 for head dims up to 96 in the 128-wide kernel, 1 for
+// head dims up to 32 in the 64-wide one; the GEMM loops, resident fragments and LDS reads skip the zero columns.
+template <typename T, int D, bool CAUSAL, bool F32OUT, bool WS = false, int KG = 4, bool BIG = false, int DVB = D / 32>
 __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const BArgs p) {
   static_assert(!(BIG && WS), "the workspace form keeps one descriptor per slice");
   using E = Elem<T>;
@@ -42,8 +44,9 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   constexpr int TILE_BYTES = BN * D * 2;
   constexpr int PIECES = TILE_BYTES / 1024;
   constexpr int PPW = PIECES / NDMA;
-  constexpr int DS = D / 16;
-  constexpr int DT = D / 32;
+  static_assert(DVB >= 1 && DVB <= D / 32, "valid 32-column blocks of a D-wide kernel");
+  constexpr int DS = 2 * DVB;
+  constexpr int DT = DVB;
   constexpr int NSTAGE = 3;
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // image 0: Q tile, image 1: dO tile
   constexpr int PX_BYTES = 32 * BN * 2;            // one key group's P tile, 16 bit

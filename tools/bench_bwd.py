@@ -14,7 +14,8 @@ CFG = {"cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096,
        "n1": (1, 64, 1024, 128, torch.bfloat16, False), "n8": (8, 64, 1024, 128, torch.bfloat16, False),
        # head dims above 128 (one wave per SIMD, three single-gradient launches)
        "d256c": (4, 8, 4096, 256, torch.bfloat16, True), "d256": (4, 8, 4096, 256, torch.bfloat16, False), "d192c": (4, 16, 4096, 192, torch.bfloat16, True),
-       "d256h": (4, 8, 4096, 256, torch.float16, True), "d160c": (4, 16, 4096, 160, torch.bfloat16, True), "d224c": (4, 8, 4096, 224, torch.bfloat16, True)}
+       "d256h": (4, 8, 4096, 256, torch.float16, True), "d160c": (4, 16, 4096, 160, torch.bfloat16, True), "d224c": (4, 8, 4096, 224, torch.bfloat16, True),
+       "d96c": (4, 32, 4096, 96, torch.bfloat16, True), "d80c": (4, 32, 4096, 80, torch.bfloat16, True), "d32c": (4, 32, 4096, 32, torch.float16, True)}
 ap = argparse.ArgumentParser()
 ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4,cfg2")
 ap.add_argument("--iters", type=int, default=20)
