@@ -944,3 +944,32 @@ def test_hip_graph_capture_and_replay(tfa, oracle, dev):
     assert torch.equal(o_g, out_ref) and torch.equal(l_g, lse_ref)
     for a, b in zip((dq_g, dk_g, dv_g), g_ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("variant", [30, 32])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 96), (torch.bfloat16, 72), (torch.float16, 32), (torch.float16, 24)])
+def test_head_dims_that_leave_the_last_column_block_empty(tfa, dev, variant, causal, dtype, D):
+    """Head dims up to 96 (128-wide kernels) / up to 32 (64-wide): the two main il kernels run the instantiation that skips the empty
+    last 32-column block (DVB = D/32 - 1: fewer MFMAs, fragment reads and O registers; same LDS tiles).  Forced per variant, ragged
+    lengths and GQA included, against a device fp32 reference at the reference's 1e-2 bar (LSE 1e-4)."""
+    from tiny_flash_attention_amd import _lib, ops
+
+    g = torch.Generator(device=dev).manual_seed(1234 + D)
+    _lib.set_variant(variant)
+    try:
+        for B, H, Hk, Nq, Nk in ((2, 8, 8, 1024, 1024), (1, 8, 2, 777, 1301), (1, 4, 4, 512, 2048)):
+            mk = lambda n, h: torch.empty((B, h, n, D), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(dtype)
+            q, k, v = mk(Nq, H), mk(Nk, Hk), mk(Nk, Hk)
+            sc = 1.0 / math.sqrt(D)
+            out, lse = ops.flash_attn_fwd(q, k, v, causal, sc)
+            kf, vf = k.float().repeat_interleave(H // Hk, 1), v.float().repeat_interleave(H // Hk, 1)
+            s_ = torch.matmul(q.float(), kf.transpose(2, 3)) * sc
+            if causal:
+                i = torch.arange(Nq, device=dev)[:, None] + (Nk - Nq)
+                s_ = s_.masked_fill(torch.arange(Nk, device=dev)[None, :] > i, float("-inf"))
+            ref = torch.matmul(torch.softmax(s_, dim=-1), vf)
+            assert (out.float() - ref).abs().max().item() <= 1e-2, (B, H, Hk, Nq, Nk)
+            assert (lse - torch.logsumexp(s_, dim=-1)).abs().max().item() <= 1e-4
+    finally:
+        _lib.set_variant(-1)

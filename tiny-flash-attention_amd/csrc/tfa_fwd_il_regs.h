@@ -43,12 +43,12 @@ template <typename T, typename X8> static __device__ __forceinline__ void o_mfma
 }
 template <int DT> static __device__ __forceinline__ void o_zero() {
   asm volatile(".irp r," TFA_O_LIST01 "\n\tv_mov_b32 v[\\r], 0\n\t.endr" ::: TFA_O_CLOB0, TFA_O_CLOB1);
-  if constexpr (DT == 4) asm volatile(".irp r," TFA_O_LIST23 "\n\tv_mov_b32 v[\\r], 0\n\t.endr" ::: TFA_O_CLOB2, TFA_O_CLOB3);
+  if constexpr (DT > 2) asm volatile(".irp r," TFA_O_LIST23 "\n\tv_mov_b32 v[\\r], 0\n\t.endr" ::: TFA_O_CLOB2, TFA_O_CLOB3);
 }
 // O *= alpha (per lane); the leading s_nops cover the MFMA-write -> VALU-read distance (cold path)
 template <int DT> static __device__ __forceinline__ void o_scale(float alpha) {
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t.irp r," TFA_O_LIST01 "\n\tv_mul_f32 v[\\r], v[\\r], %0\n\t.endr" ::"v"(alpha) : TFA_O_CLOB0, TFA_O_CLOB1);
-  if constexpr (DT == 4)
+  if constexpr (DT > 2)
     asm volatile(".irp r," TFA_O_LIST23 "\n\tv_mul_f32 v[\\r], v[\\r], %0\n\t.endr" ::"v"(alpha) : TFA_O_CLOB2, TFA_O_CLOB3);
 }
 // out[r] = O[d tile DI][r] * inv

@@ -63,7 +63,10 @@ namespace tfa {
 // AB: timing-only ablation bits of the fast path (results are wrong when set; tools/ablate_il.py)
 constexpr int ILAB_NOEXP = 1, ILAB_NODMA = 2, ILAB_NOBARRIER = 4, ILAB_NOMAX = 8, ILAB_NOQK = 16, ILAB_NOPV = 32, ILAB_NOKREAD = 64, ILAB_NOVREAD = 128;
 
-template <typename T, int D, int NW, bool CAUSAL, bool F32OUT, int VF, int AB = 0>
+// DVB: 32-wide column blocks that can hold valid head-dim columns (default: all of them).  D / 32 - 1 is instantiated for the two main
+// kernels: head dims up to 96 (128 wide) / up to 32 (64 wide) skip the MFMAs, fragment reads and O registers of the empty last block;
+// the LDS tiles and every address keep the full width.
+template <typename T, int D, int NW, bool CAUSAL, bool F32OUT, int VF, int AB = 0, int DVB = D / 32>
 __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) void fwd_kernel_il(const KArgs p) {
   using E = Elem<T>;
   using X8 = typename E::x8;
@@ -77,8 +80,10 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   constexpr int TILE_BYTES = BN * D * 2;
   constexpr int PIECES = TILE_BYTES / 1024;
   constexpr int PPW = PIECES / NWG;                // DMA pieces per wave per tensor per tile
-  constexpr int DS = D / 16;
-  constexpr int DT = D / 32;
+  static_assert(DVB >= 1 && DVB <= D / 32, "valid 32-column blocks of a D-wide kernel");
+  constexpr int DS = 2 * DVB;                      // k-slots that are multiplied
+  constexpr int DT = DVB;                          // 32-column tiles of O that exist
+  constexpr int DT_L = D / 32;                     // ... as the V tile's LDS layout counts them
   constexpr int N1 = 2 * DS;                       // QK^T MFMAs per tile
   constexpr int N2 = 4 * DT;                       // PV MFMAs per tile
   // (settled by same-process A/Bs, all within +-0.7 %: read-ahead 3 or 4, 19 or 24 elements in part 1, a uniform element-to-slot
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     {
       const int o = pc * 1024 + lane * 16;
       const int sub = o >> 9, R = (o >> 6) & 7, pcs = (o >> 4) & 3;
-      const int dt = sub % DT, sh = sub / DT;
+      const int dt = sub % DT_L, sh = sub / DT_L;
       const int key = 16 * (sh >> 1) + 4 * (sh & 1) + 8 * (R >> 2) + (R & 3);
       v_src[i] = (dt * 4 + pcs) * 8 < p.dv ? key * (int)p.vs_n * 2 + ((dt * 4 + pcs) << 4) : (int)TFA_OOB;
     }
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   unsigned k_rd_addr = lds_base + qi * (D * 2) + ((hi ^ k_swz<D>(qi)) << 4);
   asm volatile("" : "+v"(k_rd_addr));
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-  const int v_rd_base = (hi * DT << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
+  const int v_rd_base = (hi * DT_L << 9) + ((i16 >> 2) << 6) + (g16 << 5) + ((i16 & 3) << 3);
   const float sc = p.scale_log2;
   int nt_total = 0, n_slow = 0;
   unsigned long long tw_wait = 0, tw_bar = 0;   // TFA_IL_TRACEWAIT debug sums
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       return __builtin_bit_cast(X8, *reinterpret_cast<lds_u32x4*>(a));
     };
     auto v_frag = [&](const char* vb, int i) -> X8 {   // fragment of PV MFMA i: key slot i/DT, d tile i%DT
-      const char* a = vb + v_rd_base + ((i / DT) * 2 * DT << 9) + ((i % DT) << 9);
+      const char* a = vb + v_rd_base + ((i / DT) * 2 * DT_L << 9) + ((i % DT) << 9);
       s16x4 lo = lds_read_tr16_b64(a);
       s16x4 hh = lds_read_tr16_b64(a + 256);
       return __builtin_bit_cast(X8, __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7));
