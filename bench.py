@@ -28,7 +28,7 @@ Protocol (what happens, in order; all of it is reported in the JSON line):
   5. K steps in the reference's own harness style: host timer, synchronize after EVERY call
      (flash_attention_cutlass/test.py:30-40) -> `reference_harness_ms`.
   6. one traced launch -> sustained shader clock.
-  7. rank 0, N=1, forward mode: `secondary` — <= 8 s of driver-timed twins of the other numbers quoted in DESIGN.md: BASELINE
+  7. rank 0, N=1, forward mode: `secondary` — <= 11 s of driver-timed twins of the other numbers quoted in DESIGN.md: BASELINE
      configs 2 and 4, the headline shape non-causal, one GQA decode shape (HBM-bound) and the headline backward.
   8. rank 0, N=1: the reference's CPU paths on the host cores (`cpu_baseline`: the C path on a bounded
      sample of the same workload; `cpu_baseline_python`: the pure-Python path on its own config 1).
@@ -132,7 +132,7 @@ def cpu_baseline_python(reps=3):
     }
 
 
-def secondary_measurements(dev, budget_s=8.0):
+def secondary_measurements(dev, budget_s=11.0):
     """Driver-timed twins of the builder-run numbers: after the headline's timed region, <= budget_s in
     total, the other BASELINE configs, one decode shape and the headline backward — each: 0.25 s of untimed launches, then
     one HIP-event pair around as many launches as fit its share of the budget.  `frac` = fraction of the 2.5 PF bf16 MFMA
@@ -148,6 +148,10 @@ def secondary_measurements(dev, budget_s=8.0):
         ("cfg4", "fwd", (1, 16, 16, 16384, 16384, 128, torch.bfloat16, False)),
         ("decode_B64_H32_Hk8_Nq1_Nk8192", "fwd", (64, 32, 8, 1, 8192, 128, torch.bfloat16, True)),
         ("cfg3_bwd", "bwd", (4, 32, 32, 4096, 4096, 128, torch.bfloat16, True)),
+        # head dims above 128 (the reference's "classic" 8 heads x 256, flash_attention_cutlass/test.py:44-48): forward, backward, decode
+        ("d256_fwd", "fwd", (4, 8, 8, 4096, 4096, 256, torch.bfloat16, True)),
+        ("d256_bwd", "bwd", (4, 8, 8, 4096, 4096, 256, torch.bfloat16, True)),
+        ("decode_d256_B1_H16_Nq1_Nk65536", "split", (1, 16, 16, 1, 65536, 256, torch.bfloat16, True)),
     ]
     share = budget_s / len(cases)
     res = {}
@@ -167,6 +171,12 @@ def secondary_measurements(dev, budget_s=8.0):
                 pb = ops.make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, causal, sc)
                 call = lambda: _lib.check(L.tfa_bwd(C.byref(pb), sptr))
                 L.tfa_bwd_work(C.byref(pb), C.byref(fl), C.byref(by))
+            elif mode == "split":                            # what the reference-named entry points do for decode-like calls
+                splits = int(L.tfa_fwd_suggest_splits(C.byref(p)))
+                L.tfa_fwd_splitkv_workspace.restype = C.c_longlong
+                ws = torch.empty((max(int(L.tfa_fwd_splitkv_workspace(C.byref(p), splits)), 4),), dtype=torch.float32, device=dev)
+                call = (lambda: _lib.check(L.tfa_fwd_splitkv(C.byref(p), splits, C.c_void_p(ws.data_ptr()), sptr))) if splits > 1 else (lambda: _lib.check(L.tfa_fwd(C.byref(p), sptr)))
+                L.tfa_fwd_work(C.byref(p), C.byref(fl), C.byref(by))
             else:
                 call = lambda: _lib.check(L.tfa_fwd(C.byref(p), sptr))
                 L.tfa_fwd_work(C.byref(p), C.byref(fl), C.byref(by))
@@ -196,7 +206,8 @@ def secondary_measurements(dev, budget_s=8.0):
                          "mode": mode, "ms": ms, "launches": n, "tflops": tfs, "frac": tfs / PEAK_TFLOPS_BF16,
                          "algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
                          "bound": "hbm" if name.startswith("decode") else "mfma",
-                         "kernel_variant": _lib.variant_name(L.tfa_fwd_variant(C.byref(p))) if mode == "fwd" else "bwd (delta + dQ + dK + dV launches)"}
+                         "kernel_variant": _lib.variant_name(L.tfa_fwd_variant(C.byref(p))) if mode == "fwd" else
+                                           (f"tfa_fwd_splitkv, {splits} chunks in one launch + merge" if mode == "split" else "bwd (delta + dQ + dK + dV launches)")}
             del q, k, v, out, lse
         except Exception as e:   # a report, never a reason to lose the headline line
             res[name] = {"error": repr(e)}
