@@ -175,7 +175,8 @@ int tfa_merge(const float* o_parts, const float* lse_parts, int nparts, int64_t 
  * chunk (LDS-DMA kernel, 64 / 128 / 256 wide), partials go to `workspace`, tfa_merge writes *p's out (contiguous (B,H,Nq,D)) and lse.
  * (b,h) slices of 2 GiB and more: one launch of tfa_fwd's windowed kernel per chunk instead; when such a launch leaves
  * the chip mostly idle the launches are forked over four side streams owned by the calling thread and joined into `stream` before the
- * merge (event fork / join: legal inside a stream capture).  Everything the call enqueues is ordered before later work on `stream`.
+ * merge (event fork / join: legal inside a stream capture — the streams and events are created on the thread's first such call, so make
+ * one call outside a capture first).  Everything the call enqueues is ordered before later work on `stream`.
  * workspace: tfa_fwd_splitkv_workspace(p, splits) floats (16-byte aligned); negative return = TFA_ERR_*. */
 long long tfa_fwd_splitkv_workspace(const tfa_fwd_params* p, int splits);
 int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void* stream);
