@@ -37,6 +37,20 @@ static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsi
       : "memory");
 }
 
+// lds_dma16 with the non-temporal hint: K/V bytes no other workgroup will ask for (decode: one query block per K/V head)
+static __device__ __forceinline__ void lds_dma16_nt(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, int voffset) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %2, %3, 0 offen nt lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_addr), "v"(voffset), "s"(rs)
+      : "memory");
+}
+
 // LDS-DMA without saving/restoring M0 around it (2 SALU less per piece in the hot loop).  Safe only because nothing else
 // in the kernels that call it (fwd_kernel_il, bwd_kernel) uses M0 (hipcc emits no M0 user here: LDS instructions need none on gfx9+, SGPR spills use immediate
 // lane indices); tests/test_abi.py disassembles the library and fails if that ever changes.
@@ -87,6 +101,7 @@ static __device__ __forceinline__ void lds_dma16_m0_fresh(__amdgpu_buffer_rsrc_t
 constexpr int VF_PERSIST = 2048;   // launch one workgroup per CU and walk the work items (else one item per workgroup)
 constexpr int VF_2BUF = 4096;      // two LDS tile buffers (64 KiB at D=128): two 4-wave workgroups fit one CU
 constexpr int VF_LDSEPI = 16384;   // epilogue: transpose O through LDS and store whole rows (16-byte coalesced stores)
+constexpr int VF_DMA_NT = 1 << 27;   // K/V tiles streamed with the non-temporal hint (decode over a K/V cache larger than the memory-side cache)
 constexpr int VF_PRIO = 1024;   // s_setprio(1) around the MFMA clusters (experiment, tests/tools/ab.py)
 
 // The kernel walks a STREAM of query blocks: workgroup g takes work items g, g+G, g+2G, ... (G =
@@ -213,12 +228,20 @@ __global__ __launch_bounds__(NW * 64, D > 128 ? 1 : 2) void fwd_kernel_dma(const
     k.k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h + koff), 0, kb, 0x00020000);
     k.v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h + voff), 0, vb, 0x00020000);
   };
+  // VF_DMA_NT: every K/V byte is read by exactly one workgroup (one query block per head, GQA rows packed) AND the cache is larger
+  // than the 256 MB memory-side cache can keep from one decode step to the next (the host decides: tfa_api.hip) -> non-temporal
+  // loads: +8..16 % on caches of 1 GB; caches that fit are served faster without the hint (-15 %: profiles/r03_decode_nt_ab.txt)
   auto dma_issue = [&](const Blk& k, int j, int buf) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int pc = wave * PPW + i;
-      lds_dma16(k.k_rs, lds_base + buf * TILE_BYTES + pc * 1024, k_src[i] + j * k_tile_stride);
-      lds_dma16(k.v_rs, lds_base + (NBUF + buf) * TILE_BYTES + pc * 1024, v_src[i] + j * v_tile_stride);
+      if constexpr ((VF & VF_DMA_NT) != 0) {
+        lds_dma16_nt(k.k_rs, lds_base + buf * TILE_BYTES + pc * 1024, k_src[i] + j * k_tile_stride);
+        lds_dma16_nt(k.v_rs, lds_base + (NBUF + buf) * TILE_BYTES + pc * 1024, v_src[i] + j * v_tile_stride);
+      } else {
+        lds_dma16(k.k_rs, lds_base + buf * TILE_BYTES + pc * 1024, k_src[i] + j * k_tile_stride);
+        lds_dma16(k.v_rs, lds_base + (NBUF + buf) * TILE_BYTES + pc * 1024, v_src[i] + j * v_tile_stride);
+      }
     }
   };
   X8 qf[DS];
