@@ -151,6 +151,9 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant, int row_mod = 
   if (nbh * a->nwork >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
   a->nbh = (int)nbh;
   a->dbg = g_dbg_flags;
+  // K and V together beyond 768 MiB: the cache will not survive in the memory-side cache until the next call -> decode kernels may
+  // stream it with the non-temporal hint (tfa_fwd_kernel_il.h / tfa_fwd_kernel_dma.h: kv_private, VF_DMA_NT)
+  if ((long long)p->B * p->Hk * p->Nk * p->D * 4 >= (768ll << 20)) a->dbg |= 1 << 20;
   a->row_mod = row_mod;
   a->dv = p->D;
   return TFA_OK;
@@ -407,9 +410,7 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
   if (st != TFA_OK) return st;
   a.nsplit = ns;
   a.chunk = ch;
-  // K and V together beyond 768 MiB: the cache will not survive in the memory-side cache until the next decode step -> the kernel may
-  // stream it with the non-temporal hint (tfa_fwd_kernel_dma.h: kv_private)
-  if ((long long)q.B * q.Hk * q.Nk * q.D * 4 >= (768ll << 20)) a.dbg |= 1 << 20;
+
   a.o_part_stride = rows * p->D;
   a.lse_part_stride = rows;
   if ((long long)a.nbh * a.nwork * ns >= (long long)0x7fffffff) return TFA_ERR_SHAPE;

@@ -186,7 +186,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const int k_tile_stride = (KSPLIT ? 2 : 1) * BN * (int)p.ks_n * 2;
   const int v_tile_stride = (KSPLIT ? 2 : 1) * BN * (int)p.vs_n * 2;
 
-  const bool kv_private = p.H == p.Hk;             // (query heads that share a K/V head share its tiles in L2: no streaming hint then)
+  // (query heads that share a K/V head share its tiles in L2: no streaming hint then; nor for a K/V cache that the 256 MB memory-side
+  //  cache can keep until the next decode step — the host sets KArgs::dbg bit 1 << 20 from 768 MiB on: profiles/r03_decode_nt_ab.txt)
+  const bool kv_private = p.H == p.Hk && (p.dbg & (1 << 20)) != 0;
   auto dma_k1 = [&](int t, int buf, int i) {
     if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(kbase, k_bytes, (unsigned long long)t * (unsigned)k_tile_stride), lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i]);
     else if ((VF & VF_IL_IDLE) && IL_DECODE_NT && kv_private) lds_dma16_m0_nt(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
