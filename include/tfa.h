@@ -182,8 +182,8 @@ long long tfa_fwd_splitkv_workspace(const tfa_fwd_params* p, int splits);
 int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void* stream);
 /* The split count a host that can provide a workspace should use for *p: 1 = call tfa_fwd (the grid fills the chip, or the
  * keys are too few to be worth a merge), >= 2 = call tfa_fwd_splitkv with that many chunks (decode-like shapes: B*H*ceil(Nq/128)
- * workgroups on a quarter of the CUs or fewer, at least 4096 keys, causal only when Nq <= Nk/4; measured 3-9x on B1 H32 Nq1
- * Nk16k..64k, B1 H8 Nq16 Nk32k, 1.7-2x on short non-causal / chunked-prefill problems with one to four heads; head dims above 128:
+ * workgroups on half of the CUs or fewer, at least 4096 keys, causal only when Nq <= Nk/4; measured 3-9x on B1 H32 Nq1
+ * Nk16k..64k, B1 H8 Nq16 Nk32k, 1.7-2x on short non-causal / chunked-prefill problems with one to four heads, 1.4-1.6x when a quarter to a half of the CUs had work; head dims above 128:
  * 4-11x, K/V at 3.6-5.5 TB/s; at most 4 for the one-launch-per-chunk route of slices beyond 2 GiB: 1.4-1.8x).
  * The reference-named bindings (attention_cutlass / attention_cuda / _kernels and their Python mirrors) follow it. */
 int tfa_fwd_suggest_splits(const tfa_fwd_params* p);

@@ -150,6 +150,9 @@ def test_suggested_split_count():
     assert sug(B=1, H=8, Hk=8, Nq=16, Nk=32768) == 32
     assert sug(B=1, H=8, Hk=8, Nq=16, Nk=5000) == 4              # at least 1024 keys per chunk
     assert sug(B=8, H=32, Hk=32, Nq=1, Nk=16384) == 1            # 256 workgroups already
+    assert sug(B=4, H=32, Hk=32, Nq=1, Nk=16384) == 4            # half of the CUs: the split kernel fits two workgroups per CU
+    assert sug(B=3, H=32, Hk=32, Nq=1, Nk=16384) == 5
+    assert sug(B=5, H=32, Hk=32, Nq=1, Nk=16384) == 1            # 160 workgroups: a split no longer pays
     assert sug(B=1, H=32, Hk=32, Nq=1, Nk=2048) == 1             # short cache: the merge is not worth it
     assert sug(B=4, H=32, Hk=32, Nq=4096, Nk=4096) == 1
     assert sug(B=1, H=8, Hk=8, Nq=1, Nk=16384, D=256) == 16      # head dims above 128: the same LDS-DMA kernel, 256 wide

@@ -437,9 +437,12 @@ int tfa_fwd_suggest_splits(const tfa_fwd_params* p_in) {
   if (p->kv_offset != 0 || p->nk_total != 0 || p->B <= 0 || p->H <= 0 || p->Nq <= 0) return 1;
   const long long blocks = (long long)p->B * p->H * ((p->Nq + 127) / 128);
   const int cus = num_cus();
-  if (blocks * 4 > cus || p->Nk < 4096) return 1;
+  if (blocks * 2 > cus || p->Nk < 4096) return 1;
   if (p->is_causal && (long long)p->Nq * 4 > p->Nk) return 1;   // causal prefill: the late chunks serve few rows (measured 0.93-1.06x)
-  long long s = cus / blocks;
+  // up to a quarter of the CUs: one chunk per idle CU (measured 3-9x).  Between a quarter and a half: the split kernel fits two
+  // workgroups per CU, fill those (blocks 96: 226 -> 141 us with 4 chunks, 128: 230-240 -> 165-175 us; at 160-192 blocks a split
+  // no longer pays: profiles/r03_decode_nt_ab.txt)
+  long long s = blocks * 4 > cus ? 2 * cus / blocks : cus / blocks;
   if (s > p->Nk / 1024) s = p->Nk / 1024;
   if (s > 32) s = 32;
   // one launch per chunk (slices of 2 GiB and more): every chunk costs a launch on the host and the four side
