@@ -65,6 +65,29 @@ static const Variant kVariants[] = {
     {"il8-pair-dmaspread-epi-seam (variant 30 + the heavy pass's last tiles stream the light pass's K(0), K(1), V(0); Q before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_SEAM, 1},
     {"il8-ksplit-epi (small grids: 8 waves on one 128-row block, waves 0-3 take the even KV tiles and waves 4-7 the odd ones, merged through LDS)", 8, VF_DMA | VF_IL | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
     {"il8-ksplit-pair-epi (the key-split kernel with causal blocks paired heavy+light per workgroup: two 128-row blocks per CU)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
+    {"il8-pair-dmaspread-epi-tail (variant 30 + a wave's last tile runs a pinned softmax-behind-PV body instead of the slow path)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_TAIL, 1},
+    {"il8-pair-dmaspread-epi-pref2 (variant 30 + the light pass's first tiles and Q requested before the heavy epilogue, counted vmcnt in the light prologue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF2, 1},
+    {"il8-pair-dmaspread-epi-tail-pref2", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_TAIL | VF_IL_PREF2, 1},
+    {"il8-pair-dmaspread-epi-itertrace (debug: variant 30 with per-iteration cycle stamps of every wave, tools/trace_iters.py)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_ITERTRACE, 1},
+    {"il8-pair-dmaspread-epi-pf4 (variant 30 with LDS fragments read 4 MFMAs ahead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF4, 1},
+    {"il8-pair-dmaspread-epi-pf6 (variant 30 with LDS fragments read 6 MFMAs ahead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF6, 1},
+    {"il8-pair-dmaspread-epi-pf4-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF4 | VF_IL_ITERTRACE, 1},
+    {"il8-pair-dmaspread-epi-idle (variant 30's decode instantiation, forced: waves without a valid row skip the tile work)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE, 1},
+    {"il8-pair-dmaspread-epi-idle-pf4", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF4, 1},
+    {"il8-pair-dmaspread-epi-idle-pf6", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF6, 1},
+    {"il8-pair-dmaspread-epi-idle-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_ITERTRACE, 1},
+    {"il8-pair-dmaspread-epi-idle-pf4-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF4 | VF_IL_ITERTRACE, 1},
+    {"il8-pair-dmaspread-epi-prioalt8 (the two waves of a SIMD take turns at s_setprio 1 every 8 MFMA slots)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT8, 1},
+    {"il8-pair-dmaspread-epi-prioalt4 (turns of 4 MFMA slots)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT4, 1},
+    {"il8-pair-dmaspread-epi-dmalow (waves 0-3 issue all LDS-DMA pieces)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_DMALOW, 1},
+    {"il8-pair-dmaspread-epi-priohi (static s_setprio 1 for waves 4-7)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOHI, 1},
+    {"il8-pair-dmaspread-epi-prioalt8-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT8 | VF_IL_ITERTRACE, 1},
+    {"il8 ablation: no row max (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {"il8 ablation: no LDS fragment reads (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {"il8 ablation: no LDS-DMA (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {"il8 ablation: no exp/sum/pack, no row max (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {"il8 ablation: no softmax, no fragment reads (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {"il8 ablation: no barrier (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
@@ -100,7 +123,7 @@ static inline bool variant_built(int variant) {
   return true;
 #else
   return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant || variant == kX4D256Variant ||
-         variant == kKSplitVariant || variant == kKSplitPairVariant;
+         variant == kKSplitVariant || variant == kKSplitPairVariant || (variant >= 38 && variant <= 60);   // 38..40: round-4 A/B arms (bf16/f16 D=128 units)
 #endif
 }
 
@@ -117,6 +140,9 @@ static inline hipError_t launch_common(Kern kern, std::atomic<unsigned long long
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, a);
   return hipGetLastError();
 }
+
+// timing-only ablations of the il8 kernel (bf16, D = 128, 16-bit out): tfa_ilab_inst_bf16_128.hip, variants 55..60
+hipError_t launch_il_ablation(const KArgs& a, int variant, bool causal, hipStream_t s, LaunchGeom* g, bool dry);
 
 // The LDS-DMA kernel 256 wide, fp32 partial output: tfa_fwd_splitkv's one-launch form for head dims above 128 (tfa_dma_inst_<dtype>_256.hip)
 template <typename T>
