@@ -7,11 +7,13 @@
 
 A "step" is one forward pass of the hot path (tfa_fwd, include/tfa.h) over one synthetic batch
 already resident in HBM.  At N=1 the workload is BASELINE.json's headline configuration
-(B=4, H=32, N=4096, D=128, bf16, causal).  For N>1 every rank runs the same per-GPU batch on
-its own GPU (batch sharding, no data-path collective: each (b,h) pair is an independent
-problem, flash_attention_cutlass/csrc/flash_attention.cu:382,409,698) -> weak scaling.
-`--gather` adds the RCCL all-gather of the output shards (north_star's "trivial gather"),
-chunked over the batch so that chunk c's gather (side stream) overlaps chunk c+1's kernel.
+(config 3: B=4, H=32, N=4096, D=128, bf16, causal).  For N>1 every rank runs ITS SHARD of BASELINE
+config 5 (B=64 over 8 GPUs: per-GPU B=8, global batch 8*N — at N=8 exactly config 5) on its own GPU
+(batch sharding, no data-path collective: each (b,h) pair is an independent problem,
+flash_attention_cutlass/csrc/flash_attention.cu:382,409,698) -> weak scaling; `--config` overrides.
+For N>1 (or with `--gather`) the same JSON line carries BOTH numbers: `value` = kernel only, and the
+sub-dict `gather` = the step plus the RCCL all-gather of the output shards (north_star's "trivial
+gather"), chunked over the batch so that chunk c's gather (side stream) overlaps chunk c+1's kernel.
 `--gpus N` without a torchrun environment re-launches itself under torch.distributed.run.
 
 Protocol (what happens, in order; all of it is reported in the JSON line):
@@ -145,6 +147,8 @@ def secondary_measurements(dev, budget_s=11.0):
     cases = [
         ("cfg2", "fwd", (4, 8, 8, 1024, 1024, 64, torch.float16, False)),
         ("cfg3nc", "fwd", (4, 32, 32, 4096, 4096, 128, torch.bfloat16, False)),
+        # the headline with TFA_FWD_EXACT_MAX: P rounded at the reference's own points (element-wise rtol 1e-3, tests/test_parity_gpu.py)
+        ("cfg3_exact_max", "fwd_exact", (4, 32, 32, 4096, 4096, 128, torch.bfloat16, True)),
         ("cfg4", "fwd", (1, 16, 16, 16384, 16384, 128, torch.bfloat16, False)),
         ("decode_B64_H32_Hk8_Nq1_Nk8192", "fwd", (64, 32, 8, 1, 8192, 128, torch.bfloat16, True)),
         ("cfg3_bwd", "bwd", (4, 32, 32, 4096, 4096, 128, torch.bfloat16, True)),
@@ -163,6 +167,8 @@ def secondary_measurements(dev, budget_s=11.0):
             out = torch.empty_like(q)
             lse = torch.empty((B, H, Nq), dtype=torch.float32, device=dev)
             p = ops.make_params(q, k, v, out, lse, causal, sc)
+            if mode == "fwd_exact":
+                p.flags = _lib.TFA_FWD_EXACT_MAX
             fl, by = C.c_double(), C.c_double()
             if mode == "bwd":
                 _lib.check(L.tfa_fwd(C.byref(p), sptr))
@@ -206,12 +212,111 @@ def secondary_measurements(dev, budget_s=11.0):
                          "mode": mode, "ms": ms, "launches": n, "tflops": tfs, "frac": tfs / PEAK_TFLOPS_BF16,
                          "algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
                          "bound": "hbm" if name.startswith("decode") else "mfma",
-                         "kernel_variant": _lib.variant_name(L.tfa_fwd_variant(C.byref(p))) if mode == "fwd" else
+                         "kernel_variant": _lib.variant_name(L.tfa_fwd_variant(C.byref(p))) if mode in ("fwd", "fwd_exact") else
                                            (f"tfa_fwd_splitkv, {splits} chunks in one launch + merge" if mode == "split" else "bwd (delta + dQ + dK + dV launches)")}
             del q, k, v, out, lse
         except Exception as e:   # a report, never a reason to lose the headline line
             res[name] = {"error": repr(e)}
     return res
+
+
+def workload_text(cfg_name, world, bwd=False, bwd_form="default"):
+    B, H, N, D, dtype, causal = CONFIGS[cfg_name]
+    what = ("backward (" + bwd_form + " form: delta + dQ + dK/dV)") if bwd else "forward"
+    shard = (f" = rank's shard of BASELINE config 5 (B=64 over 8 GPUs; here global B={B * world} over {world})" if cfg_name == "cfg5" else "")
+    return (f"{cfg_name}: FlashAttention-2 {what}, per-GPU B={B} H={H} N={N} D={D} {'causal' if causal else 'full'}{shard}, "
+            f"q/k/v normal(0,0.5) resident in HBM, scale=1/sqrt(D)")
+
+
+def library_sha256():
+    import hashlib
+    from tiny_flash_attention_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def hbm_traffic_for(cfg_name, variant, bwd):
+    """HBM bytes per launch of the dominant kernel: NOT measured in this run (PMC passes perturb timing and run separately:
+    tools/prof_pmc.py -> tools/update_hbm_traffic.py -> profiles/hbm_traffic.json).  Every entry is stamped with the SHA-256 of the
+    libtfa_hip.so it was measured on; a different library (a kernel changed since) gives traffic = null and says why."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        if variant >= 0 or bwd or cfg_name not in tj:
+            return None, None
+        e = tj[cfg_name]
+        have = library_sha256()
+        if e.get("library_sha256") != have:
+            return None, (f"stale: profiles/hbm_traffic.json[{cfg_name}] was measured on library {str(e.get('library_sha256'))[:12]} "
+                          f"({e.get('git_head', '?')}), this run loaded {have[:12]} — re-run tools/prof_pmc.py + tools/update_hbm_traffic.py")
+        return e["bytes"], ("static: profiles/hbm_traffic.json (" + e.get("source", "rocprofv3 --pmc passes of this command") +
+                            f"), measured on this very library ({have[:12]}, {e.get('git_head', '?')}), not in this run")
+    except Exception as ex:
+        return None, f"unavailable: {ex!r}"
+
+
+def fake_run(args, world, rank, cfg_name, do_gather):
+    """--fake-step-ms: bench.py's multi-rank control flow on CPU tensors over gloo (tests/test_dist_cpu.py).  The HIP launch is a sleep;
+    everything a scaling run depends on — the configuration chosen for this world size, barriers, max over ranks, whole-job aggregation, the
+    gather leg through dist.OverlappedGather, the JSON fields — is the real code path's logic.  Never a measurement."""
+    import torch.distributed as dist
+    from tiny_flash_attention_amd import dist as tdist   # (imports torch only: no HIP library needed for the schedule itself)
+
+    if world > 1 or do_gather:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("gloo")
+    B, H, N, D, dtype, causal = CONFIGS[cfg_name]
+    sc = 1.0 / math.sqrt(D)
+    flops_step_rank = 4.0 * B * H * N * N * D * (0.5 if causal else 1.0)
+
+    def barrier():
+        if dist.is_initialized():
+            dist.barrier()
+
+    def region(fn, join=None):
+        for _ in range(args.warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        if join:
+            join()
+        barrier()
+        wall = time.perf_counter() - t0
+        if dist.is_initialized():
+            t = torch.tensor([wall], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall
+
+    step = lambda: time.sleep(args.fake_step_ms * 1e-3)
+    wall = region(step)
+    total = flops_step_rank * world * args.steps
+    line = {"metric": f"fwd TFLOPS + achieved %MFMA-roofline, (B={B * world},H={H},N={N},D={D}) bf16", "value": total / wall / 1e12, "unit": "TFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "fake (control-flow test: the step is a CPU sleep, the collective is gloo)",
+            "config": {"workload": workload_text(cfg_name, world), "global_batch": B * world, "per_gpu_batch": B,
+                       "parallelism": f"batch-sharded x{world}, no data-path collective"}}
+    if do_gather:
+        # tiny CPU stand-ins with the real batch dimension, so that the chunking over B is the real one
+        q = torch.zeros((B, 1, 2, 8), dtype=torch.bfloat16)
+        fn = lambda a, b_, c, cz, s_, o: (time.sleep(args.fake_step_ms * 1e-3 * a.shape[0] / B), o.fill_(float(rank + 1)))[1]
+        gth = tdist.OverlappedGather(q, q, q, causal, sc, world, rank, chunks=args.gather_chunks, fn=fn)
+        wall_g = region(gth.step, gth.join)
+        full = gth.result()
+        ok = all(bool((full[r * B:(r + 1) * B] == float(r + 1)).all()) for r in range(world))
+        line["gather"] = {"value": total / wall_g / 1e12, "unit": "TFLOP/s", "ms_per_step": wall_g / args.steps * 1e3, "chunks": gth.nchunks,
+                          "gathered_rows_ok": ok}
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return line
 
 
 def _free_port():
@@ -236,9 +341,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: cfg3 (the headline) on one GPU, the per-GPU shard of cfg5 (B=8) on several")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (-1 = library default)")
-    ap.add_argument("--gather", action="store_true", help="also all-gather the output shards over RCCL (chunked, overlapped)")
+    ap.add_argument("--gather", action="store_true", help="one GPU: also time the step + all-gather of the output (world 1 communicator); "
+                                                          "several GPUs: always on unless --no-gather")
+    ap.add_argument("--no-gather", action="store_true", help="several GPUs: skip the gather leg (kernel-only number alone)")
+    ap.add_argument("--fake-step-ms", type=float, default=0.0,
+                    help="TEST HOOK (tests/test_dist_cpu.py): replace the HIP launch by a CPU sleep of this many ms and RCCL by gloo, so that the "
+                         "multi-rank control flow (config choice, barriers, max over ranks, both legs, the JSON line) runs without GPUs; "
+                         "the line says data: fake")
     ap.add_argument("--gather-chunks", type=int, default=4, help="batch chunks of the overlapped gather")
     ap.add_argument("--precondition-s", type=float, default=2.0,
                     help="untimed, disclosed clock/power pre-conditioning before the warm-up steps (0 = off)")
@@ -258,8 +370,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    fake = args.fake_step_ms > 0
+    if not fake and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+
+    # one GPU: the headline (config 3).  Several: every rank runs its shard of config 5 (B=64 over 8 GPUs -> B=8 per GPU)
+    cfg_name = args.config or ("cfg3" if world == 1 else "cfg5")
+    B, H, N, D, dtype, causal = CONFIGS[cfg_name]
+    sc = 1.0 / math.sqrt(D)
+    do_gather = args.gather or (world > 1 and not args.no_gather)
+    bwd = args.mode == "bwd"
+
+    if fake:
+        line = fake_run(args, world, rank, cfg_name, do_gather)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        return
 
     import tiny_flash_attention_amd as tfa   # noqa: F401  (fails loudly if the HIP library is missing)
     from tiny_flash_attention_amd import _lib, ops
@@ -268,7 +394,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or args.gather:
+    if world > 1 or do_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
@@ -276,8 +402,6 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
 
-    B, H, N, D, dtype, causal = CONFIGS[args.config]
-    sc = 1.0 / math.sqrt(D)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(dtype)
     q, k, v = mk(), mk(), mk()                     # reference input recipe (test.py:13-17), resident in HBM
@@ -290,10 +414,6 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = C.c_void_p(stream.cuda_stream)
     pref = C.byref(p)
-    bwd = args.mode == "bwd"
-    gatherer = None
-    if args.gather:
-        gatherer = tdist.OverlappedGather(q, k, v, causal, sc, world, rank, chunks=args.gather_chunks)
     if bwd:
         _lib.check(L.tfa_fwd(pref, sptr))                      # out, lse of this q,k,v
         dout = mk()
@@ -309,8 +429,6 @@ def main():
     def step():
         if bwd:
             _lib.check(L.tfa_bwd(pbref, sptr))
-        elif gatherer is not None:
-            gatherer.step()
         else:
             _lib.check(L.tfa_fwd(pref, sptr))
 
@@ -335,14 +453,55 @@ def main():
         except Exception:
             return None
 
-    def timed_chunk(n):
+    def timed_chunk(n, fn=None):
+        fn = fn or step
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream)
         for _ in range(n):
-            step()
+            fn()
         b.record(stream)
         b.synchronize()
         return a.elapsed_time(b) / n
+
+    def timed_region(fn, join=None):
+        """W warm-up steps, barrier + synchronize, EXACTLY K timed steps between HIP events and a host timer, barrier + synchronize,
+        max over ranks.  Returns (wall seconds of the K steps, event ms per step on this rank)."""
+        for _ in range(args.warmup):
+            fn()
+        if join is not None:
+            join()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        # (the K launches are enqueued ~50x faster than they execute; a host stall longer than that head start opens a gap in
+        #  the stream and lands in `value` — seen once in round 2: 962 TF with every kernel at its usual 0.525 ms.  The garbage
+        #  collector is the one avoidable source; one replay of a HIP graph holding the K launches was tried and is 2.5 % SLOWER
+        #  than the loop: the runtime leaves a gap between graph kernel nodes.)
+        gc_was = gc.isenabled()
+        gc.disable()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(args.steps):
+            fn()
+        if join is not None:
+            join()                                 # the side stream's last gather belongs to the timed region
+        e1.record(stream)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
+        ev = e0.elapsed_time(e1) / args.steps
+        if dist is not None:
+            tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            wall = float(tmax.item())
+        return wall, ev
 
     # ---- 1. pre-conditioning (untimed, disclosed) -----------------------------------------------------------
     precond = {"seconds": 0.0, "launches": 0}
@@ -361,41 +520,8 @@ def main():
                    "ms_per_launch_first10": first, "ms_per_launch_last50": last,
                    "shader_clock_mhz_before": clk0, "shader_clock_mhz_after": clk1}
 
-    # ---- 2. warm-up, 3. the timed region -------------------------------------------------------------------
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    # (the K launches are enqueued ~50x faster than they execute; a host stall longer than that head start opens a gap in
-    #  the stream and lands in `value` — seen once this round: 962 TF with every kernel at its usual 0.525 ms.  The garbage
-    #  collector is the one avoidable source; one replay of a HIP graph holding the K launches was tried and is 2.5 % SLOWER
-    #  than the loop: the runtime leaves a gap between graph kernel nodes.)
-    gc_was = gc.isenabled()
-    gc.disable()
-    t0 = time.perf_counter()
-    e0.record(stream)
-    for _ in range(args.steps):
-        step()
-    if gatherer is not None:
-        gatherer.join()                            # the side stream's last gather belongs to the timed region
-    e1.record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    if gc_was:
-        gc.enable()
-    ev_ms = e0.elapsed_time(e1) / args.steps
-
-    if dist is not None:
-        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
+    # ---- 2. warm-up, 3. the timed region (kernel only: `value`) ----------------------------------------------
+    wall, ev_ms = timed_region(step)
 
     # ---- 4. per-launch durations (one event pair per launch) -------------------------------------------------
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -432,21 +558,27 @@ def main():
     value = total_flops / wall / 1e12
     achieved = flops_step_rank / (ev_ms * 1e-3) / 1e12
 
+    # ---- 6b. the gather leg: the same K steps, each followed by the chunked, overlapped all-gather of the output shards -------
+    gather_line = None
+    if do_gather and not bwd:
+        gatherer = tdist.OverlappedGather(q, k, v, causal, sc, world, rank, chunks=args.gather_chunks)
+        wall_g, ev_g = timed_region(gatherer.step, gatherer.join)
+        gather_line = {
+            "value": total_flops / wall_g / 1e12, "unit": "TFLOP/s", "ms_per_step": wall_g / args.steps * 1e3, "launch_ms": ev_g,
+            "chunks": gatherer.nchunks,
+            "gathered_bytes_per_rank_per_step": int(out.numel() * out.element_size() * world),
+            "what": "step = forward of this rank's batch slab in batch chunks + one all_gather_into_tensor per chunk on a side stream "
+                    "(chunk c's gather overlaps chunk c+1's kernel; the last gather is exposed); value = the same algorithmic flops / this time",
+        }
+        del gatherer
+
     if rank == 0:
         grid, block, ldsb = C.c_int(), C.c_int(), C.c_int()
         L.tfa_fwd_plan(pref, C.byref(grid), C.byref(block), C.byref(ldsb))
-        traffic, traffic_source = None, None
-        try:   # HBM bytes per launch: NOT measured in this run — the PMC passes perturb timing, so they are separate
-            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if args.variant < 0 and args.config in tj and not bwd:
-                traffic = tj[args.config]["bytes"]
-                traffic_source = ("static: profiles/hbm_traffic.json (" + tj[args.config].get("source", "rocprofv3 --pmc passes of this command") +
-                                  "), not measured in this run")
-        except Exception:
-            traffic = None
+        traffic, traffic_source = hbm_traffic_for(cfg_name, args.variant, bwd)
         tf = lambda ms: flops_step_rank / (ms * 1e-3) / 1e12
         line = {
-            "metric": ("bwd TFLOPS (2.5 x fwd flops)" if bwd else "fwd TFLOPS") + f" + achieved %MFMA-roofline, (B={B},H={H},N={N},D={D}) "
+            "metric": ("bwd TFLOPS (2.5 x fwd flops)" if bwd else "fwd TFLOPS") + f" + achieved %MFMA-roofline, (B={B * world},H={H},N={N},D={D}) "
                       + ("bf16" if dtype == torch.bfloat16 else "fp16"),
             "value": value,
             "unit": "TFLOP/s",
@@ -460,11 +592,10 @@ def main():
             "dtype": "bf16" if dtype == torch.bfloat16 else "f16",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: FlashAttention-2 {'backward (' + args.bwd_form + ' form: delta + dQ + dK/dV)' if bwd else 'forward'}, per-GPU B={B} H={H} N={N} D={D} "
-                            f"{'causal' if causal else 'full'}, q/k/v normal(0,0.5) resident in HBM, scale=1/sqrt(D)",
+                "workload": workload_text(cfg_name, world, bwd, args.bwd_form),
                 "global_batch": B * world,
                 "per_gpu_batch": B,
-                "parallelism": f"batch-sharded x{world}" + (f" + all_gather(out) in {gatherer.nchunks} overlapped batch chunks" if gatherer is not None else ""),
+                "parallelism": f"batch-sharded x{world}, no data-path collective" + (" (gather leg reported separately under `gather`)" if gather_line else ""),
                 "kernel_variant": _lib.variant_name(args.variant) if args.variant >= 0 else _lib.variant_name(L.tfa_fwd_variant(pref)),
                 "launch": {"grid": grid.value, "block": block.value, "lds_bytes": ldsb.value},
                 "flops_per_step_per_gpu": flops_step_rank,
@@ -496,6 +627,8 @@ def main():
                 "hbm_frac": by.value / (ev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
         }
+        if gather_line is not None:
+            line["gather"] = gather_line
         if world == 1 and not bwd and args.variant < 0 and not args.no_secondary:
             line["secondary"] = secondary_measurements(dev)
         if world == 1 and not args.no_cpu_baseline and not bwd:

@@ -116,7 +116,19 @@ typedef struct tfa_fwd_params {
  *   do — instead of the default kernels' lazily re-based row reference (same mathematics, O and LSE agree to the P-rounding
  *   bound, but the 16-bit roundings of P fall elsewhere).  Runs the burst-structured LDS-DMA kernel: head dims up to 128,
  *   (b,h) slices below 2 GiB, no GQA row packing; 10-15 % slower than the default on large grids.  For callers that compare
- *   against the reference element by element (rtol 1e-3 with fp32 output). */
+ *   against the reference element by element (rtol 1e-3 with fp32 output).
+ *
+ * WHICH TOLERANCE EACH PATH GUARANTEES (stated and asserted in tests/test_parity_gpu.py; A[i,d] = sum_j P_ij |v_jd| is the
+ * non-cancelling magnitude of an output element, eps16 = 2^-8 for bf16, 2^-11 for fp16):
+ *   every path, 16-bit output vs the exact (fp64) result:      |d| <= 1e-2                 — the reference's own bar (test.py:87)
+ *   every path, fp32 output vs the exact result:               |d| <= eps16 * A + 1e-6     — the rigorous bound of rounding P to 16 bits
+ *   every path, LSE:                                           |d| <= 1e-4, +inf exactly where a row sees no key
+ *   default kernels (lazily re-based row reference), fp32 output vs the reference's tile loop restated with THEIR rounding points:
+ *                                                              |d| <= 1e-3 * |ref| + 1e-4 * A  (<= 1e-4 of the elements may flip one rounding of P)
+ *   TFA_FWD_EXACT_MAX, fp32 output vs the reference's own tile loop (main_torch_only.py:160-270), element by element:
+ *                                                              |d| <= 1e-3 * |ref|  wherever |ref| is not a cancelling sum — BASELINE.json's rtol=1e-3,
+ *                                                              checked on whole heads of BASELINE configs 3 and 4; measured cost in bench.py's
+ *                                                              `secondary.cfg3_exact_max` (0.60 vs 0.52 ms on the headline shape). */
 #define TFA_FWD_EXACT_MAX 1
 
 /* Library version (TFA_VERSION of the build). */
@@ -240,7 +252,8 @@ int tfa_debug_bwd_split(int on);
 /* Validate *p without launching (no GPU needed). */
 int tfa_bwd_plan(const tfa_bwd_params* p);
 /* Bytes of tfa_bwd_params::workspace that switch tfa_bwd to its 5-GEMM form for *p (B*H * roundup(Nk,128) * roundup(Nq,256) * 2),
- * 0 when that form does not apply (a head's slab would reach 2 GiB), negative = TFA_ERR_*. */
+ * 0 when tfa_bwd would not use a workspace for *p (head dims above 128, (b,h) slices of 2 GiB and more, a head's slab reaching
+ * 2 GiB, the two-launch debug form), negative = TFA_ERR_*. */
 long long tfa_bwd_workspace_bytes(const tfa_bwd_params* p);
 /* Algorithmic work of one call: flops = 2.5 x the forward's (5 GEMMs of 2*Nq*Nk*D each per head, halved
  * when causal), bytes = q,k,v,out,dout read once + dq,dk,dv written once + lse. */
@@ -249,7 +262,8 @@ int tfa_bwd_work(const tfa_bwd_params* p, double* flops, double* bytes);
 int tfa_bwd_time(const tfa_bwd_params* p, int warmup, int iters, void* stream, float* avg_ms);
 
 /* Kernel-variant selector for A/B measurement and bring-up (state of the CALLING THREAD).  -1 = automatic (default).
- * tfa_num_variants() variants exist; tfa_variant_name(i) describes variant i. */
+ * Variant numbers live in [0, tfa_num_variants()); tfa_variant_available(i) says whether THIS build carries number i (the product
+ * build: the six dispatched kernels 17, 30, 32, 34, 36, 37), tfa_variant_name(i) describes it. */
 int tfa_set_variant(int variant);
 int tfa_get_variant(void);
 int tfa_num_variants(void);
@@ -270,7 +284,7 @@ int tfa_debug_set_trace(void* dev_buf);
 /* Kernel bring-up flags of the calling thread (0 = normal).  128: the trace stamps describe a causal workgroup's SECOND
  * pass (the light block) instead of the first; 256: launch the windowed-descriptor instantiation (the one slices of
  * 2 GiB and more get) whatever the slice size — tests compare its bits with the default; 8192: tfa_fwd_splitkv takes its one-launch-per-chunk
- * route (the one slices of 2 GiB and more and head dims above 128 take) on any problem; 16384: that route launches its chunks in
+ * route (the one (b,h) slices of 2 GiB and more take) on any problem; 16384: that route launches its chunks in
  * line on the caller's stream instead of forking them over the thread's side streams; the low bits insert fences / force the burst path in the x4 kernel
  * (tfa_fwd_kernel_x4.h) and are only meaningful to tools/. */
 int tfa_debug_set_flags(int flags);

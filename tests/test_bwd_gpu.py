@@ -176,6 +176,56 @@ def test_bwd_autograd_function_bnhd(tfa, oracle, dev):
         assert (g.transpose(1, 2).double().cpu() - r).abs().max().item() <= 1e-2 * max(1.0, r.abs().max().item())
 
 
+@pytest.mark.parametrize("mode", ["default", "workspace"])
+@pytest.mark.parametrize("dtype,Nk", [(torch.float16, 200), (torch.float16, 333), (torch.bfloat16, 130)])
+def test_bwd_padded_keys_with_strongly_negative_logits(tfa, oracle, dev, dtype, Nk, mode):
+    """A ragged last key block is padded with zero K/V rows; with every logit strongly negative (LSE << -11) the padded keys'
+    P = exp(0 - LSE) overflows 16 bits unless the kernel treats those keys as masked: inf in the kept dS turned into NaN in dQ
+    through 0 * inf in the workspace form (round-3 advisor finding; the fused dK/dV launch now starts the padded lanes' S at -inf).
+    Non-causal on purpose: the causal mask used to hide the padding."""
+    from tiny_flash_attention_amd import ops
+
+    B, H, Nq, D = 1, 2, 192, 64
+    g = torch.Generator().manual_seed(77)
+    q = (3.0 + torch.empty((B, H, Nq, D)).normal_(0, 0.5, generator=g)).to(dtype)
+    k = (-3.0 + torch.empty((B, H, Nk, D)).normal_(0, 0.5, generator=g)).to(dtype)
+    v = torch.empty((B, H, Nk, D)).normal_(0, 0.5, generator=g).to(dtype)
+    dout = make_dout(B, H, Nq, D, dtype, 78)
+    sc = 1.0 / math.sqrt(D)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, dout))
+    out, lse = ops.flash_attn_fwd(qd, kd, vd, False, sc)
+    assert lse.max().item() < -30.0                       # the regime of the finding
+    ws = True if mode == "workspace" else None
+    g32 = ops.flash_attn_bwd(qd, kd, vd, out, lse, dod, False, sc, grad_f32=True, workspace=ws)
+    g16 = ops.flash_attn_bwd(qd, kd, vd, out, lse, dod, False, sc, workspace=ws)
+    torch.cuda.synchronize()
+    for name, t in zip(("dq", "dk", "dv"), g32):
+        assert bool(torch.isfinite(t).all()), f"{name}: non-finite values ({mode} form)"
+    check_grads(oracle, g32, g16, q, k, v, out.cpu(), dout, False, sc, dtype)
+
+
+@pytest.mark.parametrize("mode", ["default", "workspace"])
+def test_bwd_headline_whole_head_vs_oracle(tfa, oracle, dev, mode):
+    """BASELINE config 3 at FULL size (B4 H32 N4096 D128 bf16 causal) through tfa_bwd, and one whole (b,h) head of dq, dk, dv —
+    every row, every column — against the fp64 autograd oracle within the rigorous 16-bit rounding bounds (B1)-(B3).  (MHA: a head's
+    gradients depend on that head's q, k, v, dout only, so the oracle differentiates the 4096 x 4096 problem of the one head.)"""
+    from tiny_flash_attention_amd import ops
+
+    B, H, N, D = 4, 32, 4096, 128
+    g = torch.Generator(device=dev).manual_seed(31)
+    mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(torch.bfloat16)
+    q, k, v, dout = mk(), mk(), mk(), mk()
+    sc = 1.0 / math.sqrt(D)
+    out, lse = ops.flash_attn_fwd(q, k, v, True, sc)
+    ws = True if mode == "workspace" else None
+    g32 = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, sc, grad_f32=True, workspace=ws)
+    g16 = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, sc, workspace=ws)
+    torch.cuda.synchronize()
+    b, h = 2, 13
+    sl = lambda t: t[b:b + 1, h:h + 1].cpu()
+    check_grads(oracle, tuple(sl(t) for t in g32), tuple(sl(t) for t in g16), sl(q), sl(k), sl(v), sl(out), sl(dout), True, sc, torch.bfloat16)
+
+
 def test_bwd_headline_shape_properties(tfa, dev):
     """BASELINE config 3 at full size (B4 H32 N4096 D128 bf16 causal): finite, and head independence —
     permuting heads permutes every gradient bit-exactly; dV of row-constant dO equals column sums of P."""

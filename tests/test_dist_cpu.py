@@ -172,3 +172,52 @@ def test_overlapped_gather_gloo_world2(shape, causal, chunks):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+# ---- bench.py's multi-rank control flow without GPUs (the step is a sleep, the collective is gloo: --fake-step-ms) -----------------
+def _run_bench(argv, world):
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    if world > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + argv
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + argv
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"rank 0 must print exactly ONE JSON line, got {len(lines)}: {r.stdout[-500:]}"
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_run_the_cfg5_shard_and_report_both_legs():
+    """`bench.py --gpus 2` as the driver launches it: every rank runs the per-GPU shard of BASELINE config 5 (B=8), the line names it,
+    `value` is the whole job's kernel-only rate over the max-over-ranks time and the gather leg sits in the same line."""
+    line = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--fake-step-ms", "20"], 2)
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["per_gpu_batch"] == 8 and line["config"]["global_batch"] == 16
+    assert "cfg5" in line["config"]["workload"] and "BASELINE config 5" in line["config"]["workload"]
+    assert "(B=16,H=32,N=4096,D=128)" in line["metric"]
+    per_step = 4.0 * 8 * 32 * 4096 * 4096 * 128 * 0.5
+    assert abs(line["value"] - 2 * per_step / (line["ms_per_step"] * 1e-3) / 1e12) <= 1e-6 * line["value"]   # whole-job aggregate
+    assert 20.0 <= line["ms_per_step"] <= 60.0
+    g = line["gather"]
+    assert g["gathered_rows_ok"] is True and g["chunks"] == 4 and g["ms_per_step"] >= line["ms_per_step"] * 0.9
+    assert g["value"] <= line["value"] * 1.1
+
+
+def test_bench_one_rank_keeps_the_headline_config():
+    line = _run_bench(["--steps", "3", "--warmup", "1", "--fake-step-ms", "5"], 1)
+    assert line["n_gpus"] == 1 and line["config"]["per_gpu_batch"] == 4 and line["config"]["workload"].startswith("cfg3:")
+    assert line["metric"] == "fwd TFLOPS + achieved %MFMA-roofline, (B=4,H=32,N=4096,D=128) bf16"      # BASELINE.json's metric, verbatim
+    assert "gather" not in line
+    line = _run_bench(["--steps", "2", "--warmup", "0", "--fake-step-ms", "5", "--gather"], 1)
+    assert line["gather"]["gathered_rows_ok"] is True
+
+
+def test_bench_self_spawns_its_ranks_outside_torchrun():
+    line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--fake-step-ms", "5", "--no-gather"], 1)
+    assert line["n_gpus"] == 2 and "gather" not in line and line["config"]["global_batch"] == 16

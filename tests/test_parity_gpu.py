@@ -136,12 +136,40 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", list(range(23)) + [26, 27, 28, 29, 30, 31, 32, 33, 35, 36, 37])
+def _avail(variants):
+    """Of a list of kernel variants (-1 = automatic dispatch) those this build carries: A/B arms parametrise tests only in
+    `make EXPERIMENTAL=1` builds instead of showing up as hundreds of skips in the product build."""
+    from tiny_flash_attention_amd import _lib
+
+    return [v for v in variants if v < 0 or _lib.variant_available(v)]
+
+
+PRODUCT_VARIANTS = (17, 30, 32, 34, 36, 37)     # tfa_launch.h: kVariants — the six kernels the library dispatches
+
+
+def _built_variants():
+    """Every kernel variant THIS build of the library carries and that serves head dims 64 / 128 with correct results: the product
+    kernels (minus the 256-wide one, whose shapes live in test_head_dims_*), plus — `make EXPERIMENTAL=1` builds only — the A/B arms
+    of rounds 1-3 (the round-4 arms 38..54 exist 128 wide only: tools/r4_bits.py; 55..60 are timing-only ablations)."""
+    from tiny_flash_attention_amd import _lib
+
+    return [v for v in range(_lib.num_variants()) if _lib.variant_available(v) and v != 34 and v < 38]
+
+
+def test_product_kernels_are_in_the_build(tfa):
+    """A product kernel that drops out of the build must FAIL here, not turn into skipped parametrisations."""
+    from tiny_flash_attention_amd import _lib
+
+    missing = [v for v in PRODUCT_VARIANTS if not _lib.variant_available(v)]
+    assert not missing, f"product kernel variants missing from libtfa_hip.so: {missing}"
+    assert set(PRODUCT_VARIANTS) - {34} <= set(_built_variants())
+
+
+@pytest.mark.parametrize("variant", _built_variants())
 @pytest.mark.parametrize("dtype,B,H,N,D,causal", SHAPES)
 def test_parity_all_variants(tfa, oracle, dev, variant, dtype, B, H, N, D, causal):
     from tiny_flash_attention_amd import _lib
 
-    _need_variant(variant, causal)
     _lib.set_variant(variant)
     try:
         run_case(tfa, oracle, dev, dtype, B, H, N, D, causal)
@@ -184,7 +212,45 @@ def test_exact_running_max_flag(tfa, oracle, dev, dtype, B, H, Hk, N, Nk, D, cau
     assert (rel > 1e-3).float().mean().item() <= 1e-4, f"rtol 1e-3 exceeded by {(rel > 1e-3).float().mean().item():.2e} of the elements (max rel {rel.max().item():.2e})"
 
 
-@pytest.mark.parametrize("variant", [-1, 17, 30, 31, 33, 35, 36, 37])     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
+@pytest.mark.parametrize("cfg,B,H,N,causal,heads,thr", [
+    ("cfg3", 4, 32, 4096, True, ((0, 0), (3, 31)), 0.05),      # BASELINE config 3 (headline): two whole heads
+    # BASELINE config 4 (long context): one whole head.  A non-causal row averages 16384 random values: |ref| ~ 0.01 A everywhere, so the
+    # "not a cancelling sum" line is drawn at 0.01 A there (about a third of the elements)
+    ("cfg4", 1, 16, 16384, False, ((0, 9),), 0.01),
+])
+def test_exact_running_max_flag_at_baseline_sizes(tfa, oracle, dev, cfg, B, H, N, causal, heads, thr):
+    """north_star: "matching reference output to rtol=1e-3".  With TFA_FWD_EXACT_MAX the kernel rounds P at the reference's own points
+    (main_torch_only.py:240-260 = flash_attention.cu:263-316: the exact running maximum of every 64-key tile), and then the plain
+    element-wise statement holds at the BASELINE sizes too: |out32 - ref| <= 1e-3 * |ref| on every element that is not a cancelling
+    sum (|ref| > thr * A, A = sum_j P|v|) — no absolute term, no outlier allowance beyond the 1e-4 of elements whose P sits on a
+    16-bit rounding boundary (exp2- vs exp-based exponent).  The default (lazily re-basing) kernels guarantee the reference's
+    atol 1e-2 and the bounds T2-T4 of this file's header instead; include/tfa.h says which path guarantees what."""
+    from tiny_flash_attention_amd import ops
+
+    D = 128
+    q, k, v = _headline(dev, B=B, H=H, N=N, seed=21)
+    sc = 1.0 / math.sqrt(D)
+    out32, lse = ops.flash_attn_fwd(q, k, v, causal, sc, out_f32=True, exact_max=True)
+    out16, _ = ops.flash_attn_fwd(q, k, v, causal, sc, exact_max=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out32).all())
+    for (b, h) in heads:
+        sl = lambda t: t[b:b + 1, h:h + 1].cpu()
+        qs, ks, vs = sl(q), sl(k), sl(v)
+        emu, lse_e = oracle.tiled_emulation(qs, ks, vs, causal, sc, 64, return_lse=True)
+        A = oracle.abs_weighted(qs, ks, vs, causal, sc)
+        o32 = sl(out32)
+        big = emu.abs() > thr * A
+        assert big.float().mean().item() > 0.05, "the rtol statement must cover a real share of the elements"
+        rel = ((o32 - emu).abs() / emu.abs().clamp_min(1e-30))[big]
+        frac = (rel > 1e-3).float().mean().item()
+        assert frac <= 1e-4, f"{cfg} head ({b},{h}): rtol 1e-3 exceeded by {frac:.2e} of the elements (max rel {rel.max().item():.2e})"
+        assert bool(((o32 - emu).abs() <= 1e-3 * emu.abs() + 1e-4 * A).float().mean().item() >= 1 - 1e-4)
+        assert (sl(lse) - lse_e).abs().max().item() <= 1e-4
+        assert (sl(out16).float() - emu).abs().max().item() <= 1e-2
+
+
+@pytest.mark.parametrize("variant", _avail([-1, 17, 30, 31, 33, 35, 36, 37]))     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
 @pytest.mark.parametrize("Nq,Nk,causal", [(128, 384, True), (384, 128, True), (100, 333, False), (1, 1000, True), (257, 64, False),
                                           (700, 1500, True), (1111, 1111, False)])
 def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
@@ -204,7 +270,7 @@ def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
 # head dims: every multiple of 8 up to 128 runs on the 64- or 128-wide kernel with the columns beyond D read as zeros (the
 # LDS-DMA lanes and Q loads of those 16-byte chunks are pointed out of the buffer's range) and never stored.  The reference
 # dispatches D in {32, 64, 96, 128, ...} (flash_attention_cutlass/csrc/static_switch.h:39-66).
-@pytest.mark.parametrize("variant", [-1, 17, 30, 33])
+@pytest.mark.parametrize("variant", _avail([-1, 17, 30, 33]))
 @pytest.mark.parametrize("dtype,B,H,N,D,causal", [
     (torch.bfloat16, 2, 3, 384, 96, True),
     (torch.float16, 1, 4, 512, 32, False),
@@ -359,7 +425,7 @@ def test_inputs_not_modified_and_deterministic(tfa, oracle, dev):
 # ---------------------------------------------------------------------------------------------
 # data-dependent branch: the exact "max unchanged -> skip the O rescale" path and late max jumps
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [1, 2, 5, 10, 11, 14, 15, 17, 18, 19, 20, 22, 26, 27, 28, 30, 31, 32, 33, 35])
+@pytest.mark.parametrize("variant", _avail([1, 2, 5, 10, 11, 14, 15, 17, 18, 19, 20, 22, 26, 27, 28, 30, 31, 32, 33, 35]))
 def test_late_max_jump_spike(tfa, oracle, dev, variant):
     from tiny_flash_attention_amd import _lib, ops
 
@@ -597,7 +663,7 @@ def test_long_context_cfg4_properties(tfa, dev):
     assert (out_k.float() - out[:, :2].float()).abs().max().item() <= 1e-2 * out.float().abs().max().item() + 2 ** -9
 
 
-@pytest.mark.parametrize("variant", [-1, 27, 30, 33])
+@pytest.mark.parametrize("variant", _avail([-1, 27, 30, 33]))
 def test_strided_bnhd_matches_bhnd(tfa, oracle, dev, variant):
     from tiny_flash_attention_amd import _lib, ops
 
@@ -654,7 +720,7 @@ def test_head_slices_beyond_2_gib_in_bnhd_layout(tfa, dev):
         assert (l2[0, h] - lse[0, h]).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("variant", [30, 32])
+@pytest.mark.parametrize("variant", _avail([30, 32]))
 @pytest.mark.parametrize("causal", [False, True])
 def test_windowed_instantiation_returns_the_same_bits(tfa, dev, variant, causal):
     """The windowed instantiation (launched for slices >= 2 GiB) forced onto ordinary inputs through the debug flag:
@@ -946,7 +1012,7 @@ def test_hip_graph_capture_and_replay(tfa, oracle, dev):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("variant", [30, 32])
+@pytest.mark.parametrize("variant", _avail([30, 32]))
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 96), (torch.bfloat16, 72), (torch.float16, 32), (torch.float16, 24)])
 def test_head_dims_that_leave_the_last_column_block_empty(tfa, dev, variant, causal, dtype, D):

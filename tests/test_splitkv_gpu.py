@@ -23,7 +23,13 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("variant", [-1, 17, 27, 30, "native", "native-chunks"])      # "native": tfa_fwd_splitkv, all chunks in one launch; "native-chunks": its one-launch-per-chunk route (what slices >= 2 GiB and head dims > 128 take), forced
+def _avail(variants):
+    from tiny_flash_attention_amd import _lib
+
+    return [v for v in variants if isinstance(v, str) or v < 0 or _lib.variant_available(v)]
+
+
+@pytest.mark.parametrize("variant", _avail([-1, 17, 27, 30, "native", "native-chunks"]))      # "native": tfa_fwd_splitkv, all chunks in one launch; "native-chunks": its one-launch-per-chunk route (what slices >= 2 GiB and head dims > 128 take), forced
 @pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D,causal,splits", [
     (torch.bfloat16, 1, 4, 4, 512, 512, 128, True, 2),
     (torch.bfloat16, 2, 4, 2, 300, 1000, 128, True, 3),      # GQA, ragged, Nq < Nk

@@ -153,7 +153,7 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant, int row_mod = 
   a->dbg = g_dbg_flags;
   // K and V together beyond 768 MiB: the cache will not survive in the memory-side cache until the next call -> decode kernels may
   // stream it with the non-temporal hint (tfa_fwd_kernel_il.h / tfa_fwd_kernel_dma.h: kv_private, VF_DMA_NT)
-  if ((long long)p->B * p->Hk * p->Nk * p->D * 4 >= (768ll << 20)) a->dbg |= 1 << 20;
+  a->kv_stream = ((long long)p->B * p->Hk * p->Nk * p->D * 4 >= (768ll << 20)) ? 1 : 0;
   a->row_mod = row_mod;
   a->dv = p->D;
   return TFA_OK;
@@ -220,10 +220,13 @@ int run(const tfa_fwd_params* p_in, void* stream, tfa::LaunchGeom* geom, bool dr
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipError_t e;
   const bool wide = p->D > 64;   // kernel width: 64 serves D <= 64, 128 serves 64 < D <= 128, 256 the rest (KArgs::dv = the valid part)
+#if defined(TFA_EXPERIMENTAL)
   if (variant >= 55 && variant <= 60) {                  // round-4 timing-only ablations (bf16, D = 128, 16-bit out)
     if (p->dtype != TFA_BF16 || p->D != 128 || f32out) return TFA_ERR_VARIANT;
-    e = tfa::launch_il_ablation(a, variant, causal, s, geom, dry);
-  } else if (p->D > 128) {
+    return (int)tfa::launch_il_ablation(a, variant, causal, s, geom, dry);
+  }
+#endif
+  if (p->D > 128) {
     e = (p->dtype == TFA_BF16) ? tfa::launch_x4_unit<__bf16, 256>(a, causal, f32out, 0, s, geom, dry)
                                : tfa::launch_x4_unit<_Float16, 256>(a, causal, f32out, 0, s, geom, dry);
   } else if (p->dtype == TFA_BF16) {
@@ -375,11 +378,18 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
     hipStream_t caller = reinterpret_cast<hipStream_t>(stream);
     // chunks that leave the chip mostly idle run side by side on the thread's side streams (debug flag 16384: in line)
     const long long blocks = (long long)p->B * p->H * ((p->Nq + 127) / 128);
-    SideStreams* ss = (ns >= 2 && blocks * 2 <= num_cus() && !(g_dbg_flags & 16384)) ? side_streams() : nullptr;
+    SideStreams* const pool = (ns >= 2 && blocks * 2 <= num_cus() && !(g_dbg_flags & 16384)) ? side_streams() : nullptr;
+    SideStreams* ss = pool;
+    // fork: every side stream waits for the caller's stream.  A stream that has been forked MUST be joined back before this function
+    // returns, whatever happens in between (inside a stream capture an unjoined fork invalidates the capture): `forked` counts them,
+    // and a failure half way through the fork simply runs the chunks in line on the caller's stream.
+    int forked = 0;
     if (ss) {
-      if (hipEventRecord(ss->fork, caller) != hipSuccess) ss = nullptr;
-      for (int i = 0; ss && i < kSideStreams; ++i)
-        if (hipStreamWaitEvent(ss->s[i], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
+      if (hipEventRecord(ss->fork, caller) == hipSuccess) {
+        for (; forked < kSideStreams; ++forked)
+          if (hipStreamWaitEvent(ss->s[forked], ss->fork, 0) != hipSuccess) break;
+      }
+      if (forked < kSideStreams) { (void)hipGetLastError(); ss = nullptr; }   // partial fork: joined below, chunks in line
     }
     int st_chunks = TFA_OK;
     for (int c = 0; c < ns && st_chunks == TFA_OK; ++c) {
@@ -394,22 +404,34 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
       qc.lse = ws_l + (long long)c * rows;
       st_chunks = run(&qc, ss ? (void*)ss->s[c % kSideStreams] : stream, nullptr, false);
     }
-    if (ss) {                                              // join — also after a failed launch: the caller's stream must not lose the fork
-      for (int i = 0; i < kSideStreams; ++i) {
-        if (hipEventRecord(ss->join[i], ss->s[i]) != hipSuccess || hipStreamWaitEvent(caller, ss->join[i], 0) != hipSuccess)
-          return st_chunks != TFA_OK ? st_chunks : (int)hipGetLastError();
+    // join — every forked stream, also after a failed launch or a partial fork: the caller's stream must not lose the fork
+    int st_join = TFA_OK;
+    if (forked > 0) {
+      for (int i = 0; i < forked; ++i) {                   // (`pool`, not `ss`: a partial fork dropped ss above)
+        hipError_t e = hipEventRecord(pool->join[i], pool->s[i]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(caller, pool->join[i], 0);
+        if (e != hipSuccess && st_join == TFA_OK) { st_join = (int)e; (void)hipGetLastError(); }   // keep joining the others
       }
     }
     if (st_chunks != TFA_OK) return st_chunks;
+    if (st_join != TFA_OK) return st_join;                 // (HIP errors are reported as positive status codes: tfa_strerror)
+    if (st_chunks != TFA_OK) return st_chunks;
     return tfa_merge(ws_o, ws_l, ns, rows, p->D, rows * p->D, rows, p->out, p->out_dtype, p->lse, stream);
-  }
-  {
-    tfa_fwd_params qp;                                    // GQA decode: one stream of K/V per K/V head (the workspace rows keep their order)
-    if (!(g_dbg_flags & 4096) && pack_gqa_rows(&q, &qp)) q = qp;
   }
   const int variant = tfa::kSplitVariant;                 // the LDS-DMA kernel carries the chunk dimension in its grid
   tfa::KArgs a;
-  st = validate(&q, &a, variant, 0, true);
+  {
+    // GQA decode: one stream of K/V per K/V head (the workspace rows keep their order).  As in run(): the packed description is an
+    // optimisation, never a requirement — when it does not validate (a q broadcast over heads: head stride 0; a row stride that
+    // pushes (G + 512) rows past 2 GiB) the problem runs as the caller gave it.
+    tfa_fwd_params qp;
+    st = TFA_ERR_SHAPE;
+    if (!(g_dbg_flags & 4096) && pack_gqa_rows(&q, &qp)) {
+      st = validate(&qp, &a, variant, 0, true);
+      if (st == TFA_OK) q = qp;
+    }
+    if (st != TFA_OK) st = validate(&q, &a, variant, 0, true);
+  }
   if (st != TFA_OK) return st;
   a.nsplit = ns;
   a.chunk = ch;
@@ -451,7 +473,7 @@ int tfa_fwd_suggest_splits(const tfa_fwd_params* p_in) {
   // one launch per chunk (slices of 2 GiB and more): every chunk costs a launch on the host and the four side
   // streams overlap about two launches' worth — measured 1.4-1.8x over one pass at four chunks, less at eight or sixteen
   // (tools/bench_decode_wide.py, profiles/r03_decode_wide.txt)
-  if (!one_descriptor(p) && s > 4) s = 4;
+  if (!one_descriptor(p_in) && s > 4) s = 4;            // (the caller's strides, as tfa_fwd_splitkv tests them — not the packed ones)
   return s >= 2 ? (int)s : 1;
 }
 
@@ -496,7 +518,7 @@ int tfa_set_variant(int variant) {
   const bool ablation = (variant >= 100 && variant < 612) || (variant >= 700 && variant < 716) || (variant >= 1000 && variant < 2256) ||
                         (variant >= 3000 && variant < 3256);
   if (variant != -1 && !in_table && !ablation) return TFA_ERR_VARIANT;
-  if (variant >= 0 && variant < tfa::kNumVariants && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
+  if (in_table && !tfa::variant_built(variant)) return TFA_ERR_VARIANT;
   g_variant = variant;
   return TFA_OK;
 }
@@ -507,7 +529,8 @@ int tfa_num_variants(void) { return tfa::kNumVariants; }
 int tfa_variant_available(int variant) { return tfa::variant_built(variant) ? 1 : 0; }
 const char* tfa_variant_name(int variant) {
   if (variant < 0 || variant >= tfa::kNumVariants) return "auto";
-  return tfa::kVariants[variant].name;
+  const tfa::Variant* v = tfa::variant_info(variant);
+  return v ? v->name : "(an A/B arm: not in this build, make EXPERIMENTAL=1)";
 }
 
 int tfa_fwd_work(const tfa_fwd_params* p, double* flops, double* bytes) {

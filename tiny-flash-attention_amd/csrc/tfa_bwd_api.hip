@@ -79,7 +79,9 @@ long long ws_bytes(const tfa_bwd_params* p, int* nk_pad, int* nq_pad) {
   return (long long)p->B * p->H * nk * nq * 2;
 }
 
-int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
+// ws_need (optional): receives the bytes of dS scratch the 5-GEMM form would use for *p, 0 when this problem never takes that form
+int run_bwd(const tfa_bwd_params* p, void* stream, bool dry, long long* ws_need = nullptr) {
+  if (ws_need) *ws_need = 0;
   if (!p) return TFA_ERR_NULL;
   if (!p->q || !p->k || !p->v || !p->out || !p->dout || !p->lse || !p->dq || !p->dk || !p->dv || !p->delta) return TFA_ERR_NULL;
   if (p->dtype != TFA_F16 && p->dtype != TFA_BF16) return TFA_ERR_DTYPE;
@@ -174,7 +176,10 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry) {
 #else
   const long long ws_avail = p->workspace_bytes;
 #endif
-  const bool use_ws = p->workspace != nullptr && need > 0 && ws_avail >= need && !(g_bwd_split & 1) && !wide256 && !big;
+  // the kept-dS form exists for head dims up to 128, slices below 2 GiB, and not with the two-launch debug form
+  const bool ws_form = need > 0 && !(g_bwd_split & 1) && !wide256 && !big;
+  if (ws_need) *ws_need = ws_form ? need : 0;
+  const bool use_ws = p->workspace != nullptr && ws_form && ws_avail >= need;
   if (use_ws) {
     tfa::BArgs m = a;
     m.ws = p->workspace; m.ws_nk = nk_pad; m.ws_nq = nq_pad;
@@ -240,9 +245,10 @@ long long tfa_bwd_workspace_bytes(const tfa_bwd_params* p) {
   if (!p) return TFA_ERR_NULL;
   q = *p;
   q.workspace = nullptr;
-  const int st = run_bwd(&q, nullptr, true);
+  long long need = 0;
+  const int st = run_bwd(&q, nullptr, true, &need);     // 0 where run_bwd would ignore a workspace (D > 128, slices of 2 GiB and more, debug forms)
   if (st) return st;
-  return ws_bytes(p, nullptr, nullptr);
+  return need;
 }
 
 int tfa_bwd_work(const tfa_bwd_params* p, double* flops, double* bytes) {

@@ -223,6 +223,18 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   unsigned long long tw_mem = 0, tw_bar = 0;
   const unsigned long long tw_t0 = __builtin_amdgcn_s_memtime();
 #endif
+  // Start value of the GEMM-I accumulators.  A role-0 lane whose key lies behind the last one (the padding of a ragged last key block: K and V
+  // read as zeros there) starts at -inf, so that its P is 0 — not exp(-LSE), which overflows 16 bits once a row's LSE is below -11 (fp16) and
+  // would put inf/NaN into the dS workspace and, through 0 * inf, into that query's dQ.  Sixteen registers that never change: the first MFMA of
+  // a half reads them as its C operand where it used to read the inline constant 0 — no instruction is added to the tile body.
+  f32x16 xinit;
+  {
+    const float v0 = (role == 0 && my_row >= p.Nk) ? -INFINITY : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xinit[r] = v0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(xinit[r]));   // (keep it a register array: not re-materialised per use)
+  }
   int st_next = 1;                                   // stage of tile it+1
   int st_mine = role ? NSTAGE - 1 : 0;               // stage of this wave's tile (role 1: tile it-1)
 #pragma nounroll
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
           load_stats(t);
           f32x16 x;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) x[r] = 0.f;
+          for (int r = 0; r < 16; ++r) x[r] = xinit[r];   // 0, or -inf for a role-0 lane whose key lies behind the last one (see xinit)
 #pragma unroll
           for (int sl = 0; sl < DS; ++sl) {
             const int off = k_rd_base + t * 32 * (D * 2) + (((2 * sl + hi) ^ k_rd_swz) << 4);

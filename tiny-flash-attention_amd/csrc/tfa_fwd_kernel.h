@@ -71,8 +71,8 @@ struct KArgs {
                     // read as zeros (their LDS-DMA lanes / Q loads are pointed outside the buffer) and never stored
   int dbg;          // bring-up flags (tfa_debug_set_flags; 0 in normal use).  128: the trace stamps describe the workgroup's
                     // SECOND pass (t[0] = its start) instead of the first; low bits: tfa_fwd_kernel_x4.h
-                    // Bit 1 << 20 is not a debug flag: the host sets it when K and V together reach 768 MiB (a cache the 256 MB
-                    // memory-side cache cannot keep until the next call: decode kernels may then stream K/V with the nt hint)
+  int kv_stream;    // K and V together reach 768 MiB — a cache the 256 MB memory-side cache cannot keep until the next call: decode
+                    // kernels whose K/V tiles no other workgroup reads may stream them with the non-temporal hint (set by the host)
 };
 
 template <typename T> struct Elem;

@@ -205,8 +205,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const int v_tile_stride = (KSPLIT ? 2 : 1) * BN * (int)p.vs_n * 2;
 
   // (query heads that share a K/V head share its tiles in L2: no streaming hint then; nor for a K/V cache that the 256 MB memory-side
-  //  cache can keep until the next decode step — the host sets KArgs::dbg bit 1 << 20 from 768 MiB on: profiles/r03_decode_nt_ab.txt)
-  const bool kv_private = p.H == p.Hk && (p.dbg & (1 << 20)) != 0;
+  //  cache can keep until the next decode step — the host sets KArgs::kv_stream from 768 MiB on: profiles/r03_decode_nt_ab.txt)
+  const bool kv_private = p.H == p.Hk && p.kv_stream != 0;
   const bool upper_wave = wave_id >= NW / 2;
   const bool dma_wave = !DMALOW || !upper_wave;
   if ((VF & VF_IL_PRIOHI) && upper_wave) __builtin_amdgcn_s_setprio(1);

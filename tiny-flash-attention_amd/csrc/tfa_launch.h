@@ -1,8 +1,7 @@
 // tfa_launch.h — host-side dispatch table shared by the per-(dtype, head-dim) instantiation units.
 #pragma once
-// The product library carries six kernels only (kDefaultVariant, kSmallGridVariant, kKSplitVariant, kKSplitPairVariant, kSplitVariant and kX4D256Variant); every
-// other entry of kVariants is a measured dead end or an A/B arm kept for the record and is compiled only with
-// -DTFA_EXPERIMENTAL (make EXPERIMENTAL=1).  Without the flag those variant numbers are rejected (TFA_ERR_VARIANT).
+// The product library carries six kernels (kVariants); every measured dead end and A/B arm lives in kExperimentalVariants and is compiled only
+// with -DTFA_EXPERIMENTAL (make EXPERIMENTAL=1).  Without the flag those variant numbers are rejected (TFA_ERR_VARIANT).
 #include <hip/hip_runtime.h>
 #include "tfa_host_util.h"
 #include "tfa_fwd_kernel.h"
@@ -19,85 +18,110 @@
 namespace tfa {
 
 struct Variant {
+  int id;           // the number tfa_set_variant / tfa_fwd_variant speak (stable across rounds: tools, tests and DESIGN.md cite them)
   const char* name;
   int nw;   // waves per workgroup
   int vf;   // VF_* flags
   int rb;   // 32-row query blocks per wave
 };
 
-// Keep in sync with the switch in tfa_fwd_inst.inc
+// ---- the product library: six kernels -------------------------------------------------------------------------------------
+constexpr int kDefaultVariant = 30;       // il8: 256-row blocks, issue-interleaved, 16-bit O through a separate LDS region
+constexpr int kSmallGridVariant = 32;     // il4: 128-row query blocks, two workgroups per CU
+constexpr int kX4D256Variant = 34;        // x4-d256: the only kernel for head dims above 128
+constexpr int kKSplitVariant = 36;        // il8-ksplit: grids of at most one 128-row block per CU
+constexpr int kKSplitPairVariant = 37;    // il8-ksplit-pair: causal grids of at most two 128-row blocks per CU
+constexpr int kSplitVariant = 17;         // dma4-2buf: the kernel whose grid can carry key chunks (tfa_fwd_splitkv), exact running max (TFA_FWD_EXACT_MAX)
 static const Variant kVariants[] = {
-    {"w8-gatherV (bring-up: 16-bit LDS gathers for V, no transpose read)", 8, 0, 1},
-    {"w8-trV (8 waves x 32 rows, ds_read_b64_tr_b16 for V)", 8, VF_TRREAD, 1},
-    {"w4-trV (4 waves x 32 rows, 2 workgroups/CU)", 4, VF_TRREAD, 1},
-    {"w8-trV-alwaysrescale (no exact alpha==1 skip)", 8, VF_TRREAD | VF_NOSKIP, 1},
-    {"w8-trV-pair (causal blocks paired heavy+light per workgroup)", 8, VF_TRREAD | VF_PAIR, 1},
-    {"w8-trV-pair-kpre-vpre (K and V fragments prefetched to registers)", 8, VF_TRREAD | VF_PAIR | VF_KPRE | VF_VPRE, 1},
-    {"w4-trV-pair-kpre-vpre", 4, VF_TRREAD | VF_PAIR | VF_KPRE | VF_VPRE, 1},
-    {"w8-trV-pair-vpre", 8, VF_TRREAD | VF_PAIR | VF_VPRE, 1},
-    {"pp8-pair-vpre0 (ping-pong: two wave groups half a tile apart; V fragments read in the 2nd half)", 8, VF_PP | VF_PAIR | (0 << VF_VPRE_SHIFT), 1},
-    {"pp8-pair-vpre2 (ping-pong; V fragments of 2 d-tiles read ahead in the 1st half)", 8, VF_PP | VF_PAIR | (2 << VF_VPRE_SHIFT), 1},
-    {"pp8-pair-vpre4 (ping-pong; all V fragments read ahead in the 1st half)", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT), 1},
-    {"dma8-pair (LDS-DMA staging, 3 tile buffers, counted vmcnt; 8 waves)", 8, VF_DMA | VF_PAIR, 1},
-    {"dma4-pair (LDS-DMA staging, 3 tile buffers; 4 waves, 1 workgroup/CU by LDS)", 4, VF_DMA | VF_PAIR, 1},
-    {"dma8-pair-setprio", 8, VF_DMA | VF_PAIR | VF_PRIO, 1},
-    {"swp8-pair (LDS-DMA + software-pipelined loop: softmax(j) beside QK^T(j+1), PV(j) beside rowmax(j+1))", 8, VF_DMA | VF_SWP | VF_PAIR, 1},
-    {"dma8-pair-persistent (256 workgroups walk the work items; next block prefetched behind the epilogue)", 8, VF_DMA | VF_PAIR | VF_PERSIST, 1},
-    {"dma4-pair-persistent (128-row blocks, 256 persistent workgroups)", 4, VF_DMA | VF_PAIR | VF_PERSIST, 1},
-    {"dma4-pair-2buf (128-row blocks, two LDS buffers: two workgroups per CU)", 4, VF_DMA | VF_PAIR | VF_2BUF, 1},
-    {"dma4-pair-2buf-persistent", 4, VF_DMA | VF_PAIR | VF_2BUF | VF_PERSIST, 1},
-    {"dma8-pair-2buf (two LDS buffers, prefetch distance one tile)", 8, VF_DMA | VF_PAIR | VF_2BUF, 1},
-    {"w64-pair (4 waves x 64 rows, one wave per SIMD, O accumulators pinned in AGPRs by inline-asm MFMA)", 4, VF_DMA | VF_W64 | VF_PAIR, 2},
-    {"dma4-pair-2buf-ldsepi (O leaves through LDS as whole rows, 16-byte stores)", 4, VF_DMA | VF_PAIR | VF_2BUF | VF_LDSEPI, 1},
-    {"dma8-pair-2buf-ldsepi", 8, VF_DMA | VF_PAIR | VF_2BUF | VF_LDSEPI, 1},
-    {"pp8-vpre4-gapqk8 (ping-pong + 8-cycle issue gap behind every QK^T MFMA)", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT) | (8 << VF_NOPQK_SHIFT), 1},
-    {"pp8-vpre4-gapqk8-gappv8", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT) | (8 << VF_NOPQK_SHIFT) | (8 << VF_NOPPV_SHIFT), 1},
-    {"pp8-vpre4-gapqk16", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT) | (16 << VF_NOPQK_SHIFT), 1},
-    {"il8-pair (issue-interleaved: every MFMA followed by its share of another tile's softmax; 8 waves)", 8, VF_DMA | VF_IL | VF_PAIR, 1},
-    {"il4-pair (issue-interleaved, 4 waves, two workgroups per CU)", 4, VF_DMA | VF_IL | VF_PAIR, 1},
-    {"il8-pair-dmaspread (LDS-DMA pieces issued between the first QK^T MFMAs)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD, 1},
-    {"il8-pair-dmastagger (waves 4-7 issue their LDS-DMA pieces behind the first PV MFMAs instead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_DMASTAGGER, 1},
-    {"il8-pair-dmaspread-epi (O leaves through a separate LDS region as whole rows, 16-byte stores)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {"il8-pair-dmaspread-epi-pref (+ the next pass's first tiles and Q requested before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF, 1},
-    {"il4-pair-epi (4 waves x2 workgroups per CU; O leaves through the idle tile buffers as whole rows)", 4, VF_DMA | VF_IL | VF_PAIR | VF_IL_EPI | VF_IL_EPI_INPLACE, 1},
-    {"il-x4-pair-epi (issue-interleaved, 4 waves x 64 rows: one wave per SIMD, O and Q in AGPRs, K ring of three LDS buffers)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR | VF_X4_EPI, 2},
-    {"x4-d256-pair (the x4 kernel with ONE 32-row block per wave: head dims 136..256, 128-row workgroups, O stored directly)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR, 1},
-    {"il8-pair-dmaspread-epi-seam (variant 30 + the heavy pass's last tiles stream the light pass's K(0), K(1), V(0); Q before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_SEAM, 1},
-    {"il8-ksplit-epi (small grids: 8 waves on one 128-row block, waves 0-3 take the even KV tiles and waves 4-7 the odd ones, merged through LDS)", 8, VF_DMA | VF_IL | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
-    {"il8-ksplit-pair-epi (the key-split kernel with causal blocks paired heavy+light per workgroup: two 128-row blocks per CU)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
-    {"il8-pair-dmaspread-epi-tail (variant 30 + a wave's last tile runs a pinned softmax-behind-PV body instead of the slow path)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_TAIL, 1},
-    {"il8-pair-dmaspread-epi-pref2 (variant 30 + the light pass's first tiles and Q requested before the heavy epilogue, counted vmcnt in the light prologue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF2, 1},
-    {"il8-pair-dmaspread-epi-tail-pref2", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_TAIL | VF_IL_PREF2, 1},
-    {"il8-pair-dmaspread-epi-itertrace (debug: variant 30 with per-iteration cycle stamps of every wave, tools/trace_iters.py)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_ITERTRACE, 1},
-    {"il8-pair-dmaspread-epi-pf4 (variant 30 with LDS fragments read 4 MFMAs ahead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF4, 1},
-    {"il8-pair-dmaspread-epi-pf6 (variant 30 with LDS fragments read 6 MFMAs ahead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF6, 1},
-    {"il8-pair-dmaspread-epi-pf4-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF4 | VF_IL_ITERTRACE, 1},
-    {"il8-pair-dmaspread-epi-idle (variant 30's decode instantiation, forced: waves without a valid row skip the tile work)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE, 1},
-    {"il8-pair-dmaspread-epi-idle-pf4", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF4, 1},
-    {"il8-pair-dmaspread-epi-idle-pf6", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF6, 1},
-    {"il8-pair-dmaspread-epi-idle-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_ITERTRACE, 1},
-    {"il8-pair-dmaspread-epi-idle-pf4-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF4 | VF_IL_ITERTRACE, 1},
-    {"il8-pair-dmaspread-epi-prioalt8 (the two waves of a SIMD take turns at s_setprio 1 every 8 MFMA slots)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT8, 1},
-    {"il8-pair-dmaspread-epi-prioalt4 (turns of 4 MFMA slots)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT4, 1},
-    {"il8-pair-dmaspread-epi-dmalow (waves 0-3 issue all LDS-DMA pieces)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_DMALOW, 1},
-    {"il8-pair-dmaspread-epi-priohi (static s_setprio 1 for waves 4-7)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOHI, 1},
-    {"il8-pair-dmaspread-epi-prioalt8-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT8 | VF_IL_ITERTRACE, 1},
-    {"il8 ablation: no row max (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {"il8 ablation: no LDS fragment reads (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {"il8 ablation: no LDS-DMA (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {"il8 ablation: no exp/sum/pack, no row max (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {"il8 ablation: no softmax, no fragment reads (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {"il8 ablation: no barrier (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {17, "dma4-pair-2buf (LDS-DMA, burst-structured, exact running max; 128-row blocks, two LDS buffers: two workgroups per CU)", 4, VF_DMA | VF_PAIR | VF_2BUF, 1},
+    {30, "il8-pair-dmaspread-epi (issue-interleaved, 8 waves; O leaves through a separate LDS region as whole rows, 16-byte stores; causal pairs: the light "
+         "pass is requested before the heavy pass's O stores)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF2, 1},
+    {32, "il4-pair-epi (4 waves x2 workgroups per CU; O leaves through the idle tile buffers as whole rows)", 4, VF_DMA | VF_IL | VF_PAIR | VF_IL_EPI | VF_IL_EPI_INPLACE, 1},
+    {34, "x4-d256-pair (the x4 kernel with ONE 32-row block per wave: head dims 136..256, 128-row workgroups, O stored directly)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR, 1},
+    {36, "il8-ksplit-epi (small grids: 8 waves on one 128-row block, waves 0-3 take the even KV tiles and waves 4-7 the odd ones, merged through LDS)", 8,
+     VF_DMA | VF_IL | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
+    {37, "il8-ksplit-pair-epi (the key-split kernel with causal blocks paired heavy+light per workgroup: two 128-row blocks per CU)", 8,
+     VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
 };
-constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 30;     // il8-pair-dmaspread-epi
-constexpr int kSmallGridVariant = 32;     // il4-pair-epi (128-row query blocks, two workgroups per CU)
-constexpr int kX4Variant = 33;            // il-x4-pair-epi (EXPERIMENTAL builds: the x4 kernel at head dims <= 128)
-constexpr int kX4D256Variant = 34;        // x4-d256-pair: the only kernel for head dims above 128
+constexpr int kNumProductVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+// ---- A/B arms and measured dead ends: `make EXPERIMENTAL=1` only (tfa_set_variant rejects their numbers otherwise) -------------
+constexpr int kX4Variant = 33;            // il-x4-pair-epi (the x4 kernel at head dims <= 128)
 constexpr int kSeamVariant = 35;          // il8-pair-dmaspread-epi-seam
-constexpr int kKSplitVariant = 36;        // il8-ksplit-epi: grids of at most one 128-row block per CU
-constexpr int kKSplitPairVariant = 37;    // il8-ksplit-pair-epi: causal grids of at most two 128-row blocks per CU
-constexpr int kSplitVariant = 17;         // dma4-pair-2buf: the kernel whose grid can carry key chunks (tfa_fwd_splitkv)
+#if defined(TFA_EXPERIMENTAL)
+static const Variant kExperimentalVariants[] = {
+    {0, "w8-gatherV (bring-up: 16-bit LDS gathers for V, no transpose read)", 8, 0, 1},
+    {1, "w8-trV (8 waves x 32 rows, ds_read_b64_tr_b16 for V)", 8, VF_TRREAD, 1},
+    {2, "w4-trV (4 waves x 32 rows, 2 workgroups/CU)", 4, VF_TRREAD, 1},
+    {3, "w8-trV-alwaysrescale (no exact alpha==1 skip)", 8, VF_TRREAD | VF_NOSKIP, 1},
+    {4, "w8-trV-pair (causal blocks paired heavy+light per workgroup)", 8, VF_TRREAD | VF_PAIR, 1},
+    {5, "w8-trV-pair-kpre-vpre (K and V fragments prefetched to registers)", 8, VF_TRREAD | VF_PAIR | VF_KPRE | VF_VPRE, 1},
+    {6, "w4-trV-pair-kpre-vpre", 4, VF_TRREAD | VF_PAIR | VF_KPRE | VF_VPRE, 1},
+    {7, "w8-trV-pair-vpre", 8, VF_TRREAD | VF_PAIR | VF_VPRE, 1},
+    {8, "pp8-pair-vpre0 (ping-pong: two wave groups half a tile apart; V fragments read in the 2nd half)", 8, VF_PP | VF_PAIR | (0 << VF_VPRE_SHIFT), 1},
+    {9, "pp8-pair-vpre2 (ping-pong; V fragments of 2 d-tiles read ahead in the 1st half)", 8, VF_PP | VF_PAIR | (2 << VF_VPRE_SHIFT), 1},
+    {10, "pp8-pair-vpre4 (ping-pong; all V fragments read ahead in the 1st half)", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT), 1},
+    {11, "dma8-pair (LDS-DMA staging, 3 tile buffers, counted vmcnt; 8 waves)", 8, VF_DMA | VF_PAIR, 1},
+    {12, "dma4-pair (LDS-DMA staging, 3 tile buffers; 4 waves, 1 workgroup/CU by LDS)", 4, VF_DMA | VF_PAIR, 1},
+    {13, "dma8-pair-setprio", 8, VF_DMA | VF_PAIR | VF_PRIO, 1},
+    {14, "swp8-pair (LDS-DMA + software-pipelined loop: softmax(j) beside QK^T(j+1), PV(j) beside rowmax(j+1))", 8, VF_DMA | VF_SWP | VF_PAIR, 1},
+    {15, "dma8-pair-persistent (256 workgroups walk the work items; next block prefetched behind the epilogue)", 8, VF_DMA | VF_PAIR | VF_PERSIST, 1},
+    {16, "dma4-pair-persistent (128-row blocks, 256 persistent workgroups)", 4, VF_DMA | VF_PAIR | VF_PERSIST, 1},
+    {18, "dma4-pair-2buf-persistent", 4, VF_DMA | VF_PAIR | VF_2BUF | VF_PERSIST, 1},
+    {19, "dma8-pair-2buf (two LDS buffers, prefetch distance one tile)", 8, VF_DMA | VF_PAIR | VF_2BUF, 1},
+    {20, "w64-pair (4 waves x 64 rows, one wave per SIMD, O accumulators pinned in AGPRs by inline-asm MFMA)", 4, VF_DMA | VF_W64 | VF_PAIR, 2},
+    {21, "dma4-pair-2buf-ldsepi (O leaves through LDS as whole rows, 16-byte stores)", 4, VF_DMA | VF_PAIR | VF_2BUF | VF_LDSEPI, 1},
+    {22, "dma8-pair-2buf-ldsepi", 8, VF_DMA | VF_PAIR | VF_2BUF | VF_LDSEPI, 1},
+    {23, "pp8-vpre4-gapqk8 (ping-pong + 8-cycle issue gap behind every QK^T MFMA)", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT) | (8 << VF_NOPQK_SHIFT), 1},
+    {24, "pp8-vpre4-gapqk8-gappv8", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT) | (8 << VF_NOPQK_SHIFT) | (8 << VF_NOPPV_SHIFT), 1},
+    {25, "pp8-vpre4-gapqk16", 8, VF_PP | VF_PAIR | (4 << VF_VPRE_SHIFT) | (16 << VF_NOPQK_SHIFT), 1},
+    {26, "il8-pair (issue-interleaved: every MFMA followed by its share of another tile's softmax; 8 waves)", 8, VF_DMA | VF_IL | VF_PAIR, 1},
+    {27, "il4-pair (issue-interleaved, 4 waves, two workgroups per CU)", 4, VF_DMA | VF_IL | VF_PAIR, 1},
+    {28, "il8-pair-dmaspread (LDS-DMA pieces issued between the first QK^T MFMAs)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD, 1},
+    {29, "il8-pair-dmastagger (waves 4-7 issue their LDS-DMA pieces behind the first PV MFMAs instead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_DMASTAGGER, 1},
+    {31, "il8-pair-dmaspread-epi-pref (+ the next pass's first tiles and Q requested before the epilogue, vmcnt(0) in the prologue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF, 1},
+    {33, "il-x4-pair-epi (issue-interleaved, 4 waves x 64 rows: one wave per SIMD, O and Q in AGPRs, K ring of three LDS buffers)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR | VF_X4_EPI, 2},
+    {35, "il8-pair-dmaspread-epi-seam (the heavy pass's last tiles stream the light pass's K(0), K(1), V(0); Q before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_SEAM, 1},
+    // round 4 (profiles/r04_il8_arms_ab.txt); bf16 D = 128 units only
+    {38, "il8-pair-dmaspread-epi-tail (a wave's last tile runs a pinned softmax-behind-PV body instead of the slow path)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_TAIL, 1},
+    {39, "il8-pair-dmaspread-epi-plain (round 3's default: without the light-pass prefetch of variant 30)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {40, "il8-pair-dmaspread-epi-tail-pref2", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_TAIL | VF_IL_PREF2, 1},
+    {41, "il8-pair-dmaspread-epi-itertrace (debug: per-iteration cycle stamps of every wave, tools/trace_iters.py)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_ITERTRACE, 1},
+    {42, "il8-pair-dmaspread-epi-pf4 (LDS fragments read 4 MFMAs ahead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF4, 1},
+    {43, "il8-pair-dmaspread-epi-pf6 (LDS fragments read 6 MFMAs ahead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF6, 1},
+    {44, "il8-pair-dmaspread-epi-pf4-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF4 | VF_IL_ITERTRACE, 1},
+    {45, "il8-pair-dmaspread-epi-idle (the decode instantiation, forced: waves without a valid row skip the tile work)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE, 1},
+    {46, "il8-pair-dmaspread-epi-idle-pf4", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF4, 1},
+    {47, "il8-pair-dmaspread-epi-idle-pf6", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF6, 1},
+    {48, "il8-pair-dmaspread-epi-idle-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_ITERTRACE, 1},
+    {49, "il8-pair-dmaspread-epi-idle-pf4-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF4 | VF_IL_ITERTRACE, 1},
+    {50, "il8-pair-dmaspread-epi-prioalt8 (the two waves of a SIMD take turns at s_setprio 1 every 8 MFMA slots)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT8, 1},
+    {51, "il8-pair-dmaspread-epi-prioalt4 (turns of 4 MFMA slots)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT4, 1},
+    {52, "il8-pair-dmaspread-epi-dmalow (waves 0-3 issue all LDS-DMA pieces)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_DMALOW, 1},
+    {53, "il8-pair-dmaspread-epi-priohi (static s_setprio 1 for waves 4-7)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOHI, 1},
+    {54, "il8-pair-dmaspread-epi-prioalt8-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT8 | VF_IL_ITERTRACE, 1},
+    {55, "il8 ablation: no row max (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {56, "il8 ablation: no LDS fragment reads (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {57, "il8 ablation: no LDS-DMA (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {58, "il8 ablation: no exp/sum/pack, no row max (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {59, "il8 ablation: no softmax, no fragment reads (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+    {60, "il8 ablation: no barrier (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
+};
+constexpr int kNumExperimentalVariants = sizeof(kExperimentalVariants) / sizeof(kExperimentalVariants[0]);
+#endif
+constexpr int kNumVariants = 61;          // variant numbers live in [0, kNumVariants); which of them a build carries: variant_info() != nullptr
+
+// the table entry of a variant number, or nullptr when this build does not carry it
+static inline const Variant* variant_info(int variant) {
+  for (int i = 0; i < kNumProductVariants; ++i)
+    if (kVariants[i].id == variant) return &kVariants[i];
+#if defined(TFA_EXPERIMENTAL)
+  for (int i = 0; i < kNumExperimentalVariants; ++i)
+    if (kExperimentalVariants[i].id == variant) return &kExperimentalVariants[i];
+#endif
+  return nullptr;
+}
+static inline bool variant_built(int variant) { return variant_info(variant) != nullptr; }
 
 struct LaunchGeom {
   int grid, block, lds;
@@ -116,17 +140,6 @@ static inline hipError_t launch_fwd(const KArgs& a, bool causal, bool f32out, in
   return causal ? launch_fwd_c<T, D, true>(a, f32out, variant, stream, geom, dry) : launch_fwd_c<T, D, false>(a, f32out, variant, stream, geom, dry);
 }
 
-// variants compiled into this build
-static inline bool variant_built(int variant) {
-  if (variant < 0 || variant >= kNumVariants) return false;
-#if defined(TFA_EXPERIMENTAL)
-  return true;
-#else
-  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kSplitVariant || variant == kX4D256Variant ||
-         variant == kKSplitVariant || variant == kKSplitPairVariant || (variant >= 38 && variant <= 60);   // 38..40: round-4 A/B arms (bf16/f16 D=128 units)
-#endif
-}
-
 // common tail of every launcher: report the geometry, opt in to the dynamic LDS size on this device, launch, and return
 // THIS launch's status (a sticky error left behind by unrelated earlier HIP calls is cleared first).
 template <typename Kern>
@@ -141,7 +154,7 @@ static inline hipError_t launch_common(Kern kern, std::atomic<unsigned long long
   return hipGetLastError();
 }
 
-// timing-only ablations of the il8 kernel (bf16, D = 128, 16-bit out): tfa_ilab_inst_bf16_128.hip, variants 55..60
+// timing-only ablations of the il8 kernel (bf16, D = 128, 16-bit out): experiments/csrc/tfa_ilab_inst_bf16_128.hip, variants 55..60 (EXPERIMENTAL builds)
 hipError_t launch_il_ablation(const KArgs& a, int variant, bool causal, hipStream_t s, LaunchGeom* g, bool dry);
 
 // The LDS-DMA kernel 256 wide, fp32 partial output: tfa_fwd_splitkv's one-launch form for head dims above 128 (tfa_dma_inst_<dtype>_256.hip)
@@ -174,22 +187,24 @@ static inline hipError_t launch_x4_unit(const KArgs& a, bool causal, bool f32out
 // kernels that honour KArgs::dv (head dims below the compiled width: LDS-DMA lanes / Q loads / O stores of the missing
 // 16-byte chunks go out of range): the LDS-DMA kernel, the il kernels and the x4 kernel
 static inline bool supports_padded_d(int variant) {
-  if (variant < 0 || variant >= kNumVariants) return false;
-  const int vf = kVariants[variant].vf;
-  return (vf & VF_DMA) && !(vf & (VF_SWP | VF_W64));
+  const Variant* v = variant_info(variant);
+  return v && (v->vf & VF_DMA) && !(v->vf & (VF_SWP | VF_W64));
 }
 
 // kernels that address a (b,h) slice through windowed descriptors (rsrc_at): the slice may exceed 2 GiB
 static inline bool windowed_slices(int variant) {
-  if (variant < 0 || variant >= kNumVariants) return false;
   return variant == kDefaultVariant || variant == kSmallGridVariant;   // the dispatched il kernels have a windowed instantiation
 }
 
 static inline int block_m_of(int variant) {
-  const int rows = kVariants[variant].nw * 32 * kVariants[variant].rb;
-  return (kVariants[variant].vf & VF_IL_KSPLIT) ? rows / 2 : rows;   // two groups of waves share one query block
+  const Variant* v = variant_info(variant);
+  if (!v) return 256;
+  const int rows = v->nw * 32 * v->rb;
+  return (v->vf & VF_IL_KSPLIT) ? rows / 2 : rows;   // two groups of waves share one query block
 }
-static inline bool uses_dma(int variant) { return (kVariants[variant].vf & VF_DMA) != 0; }
-static inline bool pairs_causal(int variant) { return (kVariants[variant].vf & VF_PAIR) != 0; }
+static inline bool pairs_causal(int variant) {
+  const Variant* v = variant_info(variant);
+  return v && (v->vf & VF_PAIR) != 0;
+}
 
 }  // namespace tfa
