@@ -64,6 +64,10 @@ constexpr int VF_IL_PF4 = 1, VF_IL_PF6 = 2;   // (A/B arms; the bits are VF_TRRE
 constexpr int VF_IL_PRIOALT8 = 8, VF_IL_PRIOALT4 = 16;   // the two waves of a SIMD take turns at s_setprio 1, every 8 / 4 MFMA slots: age-based arbitration lets the older
                                                          // wave run ahead and the younger finish the tile alone (a quarter of every iteration at one wave's efficiency)
 constexpr int VF_IL_DMALOW = 32;                         // waves 0..NW/2-1 (the older of every SIMD) issue ALL LDS-DMA pieces: the arbitration losers carry less
+constexpr int VF_IL_LIGHTFIRST = 512;                    // causal pairs: the LIGHT block first, then the heavy one.  Heavy-first, the eight workgroups of a head stream
+                                                         // the head's tiles in lockstep and then re-read tiles 0.. for their light passes long after the L2 dropped them
+                                                         // (the light passes are a quarter of all tile reads: the L2 hit rate of 0.73); light-first, the heavy passes
+                                                         // follow each other four tiles apart behind tiles a light pass has just fetched
 constexpr int VF_IL_PRIOHI = 256;                        // static s_setprio 1 for waves NW/2.. (the younger of every SIMD)
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
                                          // so the two waves of a SIMD never sit in an LDS-DMA issue stall at the same time
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   auto own_tiles = [&](int ntg) -> int { return KSPLIT ? (ntg - grp + 1) >> 1 : ntg; };   // this wave's share of ntg tiles of the head
   auto key0_of = [&](int t) -> int { return (KSTEP * t + grp) * BN; };                        // first key of the wave's tile t
   auto block_of = [&](int pass) -> int {
+    if (PAIR && (VF & VF_IL_LIGHTFIRST)) return (pass == 0 && (p.nmb - 1 - wi) != wi) ? wi : (p.nmb - 1 - wi);
     if (PAIR) return pass == 0 ? (p.nmb - 1 - wi) : wi;
     return CAUSAL ? (p.nmb - 1 - wi) : wi;
   };

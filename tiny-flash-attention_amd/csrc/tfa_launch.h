@@ -48,8 +48,10 @@ constexpr int kNumProductVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // ---- A/B arms and measured dead ends: `make EXPERIMENTAL=1` only (tfa_set_variant rejects their numbers otherwise) -------------
 constexpr int kX4Variant = 33;            // il-x4-pair-epi (the x4 kernel at head dims <= 128)
 constexpr int kSeamVariant = 35;          // il8-pair-dmaspread-epi-seam
-#if defined(TFA_EXPERIMENTAL)
+// (-DTFA_R4_ARMS alone carries the round-4 arms 38.. without the older kernels: tools/r4_quick.sh builds that into lib_x/ in a minute)
+#if defined(TFA_EXPERIMENTAL) || defined(TFA_R4_ARMS)
 static const Variant kExperimentalVariants[] = {
+#if defined(TFA_EXPERIMENTAL)
     {0, "w8-gatherV (bring-up: 16-bit LDS gathers for V, no transpose read)", 8, 0, 1},
     {1, "w8-trV (8 waves x 32 rows, ds_read_b64_tr_b16 for V)", 8, VF_TRREAD, 1},
     {2, "w4-trV (4 waves x 32 rows, 2 workgroups/CU)", 4, VF_TRREAD, 1},
@@ -82,6 +84,7 @@ static const Variant kExperimentalVariants[] = {
     {31, "il8-pair-dmaspread-epi-pref (+ the next pass's first tiles and Q requested before the epilogue, vmcnt(0) in the prologue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF, 1},
     {33, "il-x4-pair-epi (issue-interleaved, 4 waves x 64 rows: one wave per SIMD, O and Q in AGPRs, K ring of three LDS buffers)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR | VF_X4_EPI, 2},
     {35, "il8-pair-dmaspread-epi-seam (the heavy pass's last tiles stream the light pass's K(0), K(1), V(0); Q before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_SEAM, 1},
+#endif
     // round 4 (profiles/r04_il8_arms_ab.txt); bf16 D = 128 units only
     {38, "il8-pair-dmaspread-epi-tail (a wave's last tile runs a pinned softmax-behind-PV body instead of the slow path)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_TAIL, 1},
     {39, "il8-pair-dmaspread-epi-plain (round 3's default: without the light-pass prefetch of variant 30)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
@@ -100,6 +103,8 @@ static const Variant kExperimentalVariants[] = {
     {52, "il8-pair-dmaspread-epi-dmalow (waves 0-3 issue all LDS-DMA pieces)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_DMALOW, 1},
     {53, "il8-pair-dmaspread-epi-priohi (static s_setprio 1 for waves 4-7)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOHI, 1},
     {54, "il8-pair-dmaspread-epi-prioalt8-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT8 | VF_IL_ITERTRACE, 1},
+    {61, "il8-pair-dmaspread-epi-pref2-lightfirst (variant 30 with the light block of a causal pair first)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF2 | VF_IL_LIGHTFIRST, 1},
+    {62, "il8-pair-dmaspread-epi-lightfirst (round 3's default with the light block first)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_LIGHTFIRST, 1},
     {55, "il8 ablation: no row max (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
     {56, "il8 ablation: no LDS fragment reads (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
     {57, "il8 ablation: no LDS-DMA (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
@@ -109,13 +114,13 @@ static const Variant kExperimentalVariants[] = {
 };
 constexpr int kNumExperimentalVariants = sizeof(kExperimentalVariants) / sizeof(kExperimentalVariants[0]);
 #endif
-constexpr int kNumVariants = 61;          // variant numbers live in [0, kNumVariants); which of them a build carries: variant_info() != nullptr
+constexpr int kNumVariants = 63;          // variant numbers live in [0, kNumVariants); which of them a build carries: variant_info() != nullptr
 
 // the table entry of a variant number, or nullptr when this build does not carry it
 static inline const Variant* variant_info(int variant) {
   for (int i = 0; i < kNumProductVariants; ++i)
     if (kVariants[i].id == variant) return &kVariants[i];
-#if defined(TFA_EXPERIMENTAL)
+#if defined(TFA_EXPERIMENTAL) || defined(TFA_R4_ARMS)
   for (int i = 0; i < kNumExperimentalVariants; ++i)
     if (kExperimentalVariants[i].id == variant) return &kExperimentalVariants[i];
 #endif

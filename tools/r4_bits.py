@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--base", type=int, default=30)
 ap.add_argument("--arms", default="38,39,40")
 ap.add_argument("--dims", default="128")
+ap.add_argument("--dtypes", default="bf16,f16", help="the round-4 arms of lib_x exist in the bf16 units only: --dtypes bf16")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 arms = [int(x) for x in a.arms.split(",")]
@@ -22,7 +23,7 @@ SHAPES = [(1, 2, 2, 256, 256, True), (1, 2, 2, 256, 256, False), (2, 3, 3, 512, 
           (1, 2, 2, 777, 777, True), (1, 2, 1, 513, 513, True), (1, 2, 2, 64, 64, True), (1, 2, 2, 128, 128, True), (1, 2, 2, 192, 192, True)]
 bad = 0
 for D in [int(x) for x in a.dims.split(",")]:
-    for dt in (torch.bfloat16, torch.float16):
+    for dt in [{"bf16": torch.bfloat16, "f16": torch.float16}[x] for x in a.dtypes.split(",")]:
         for f32 in (False, True):
             for (B, H, Hk, Nq, Nk, causal) in SHAPES:
                 g = torch.Generator(device="cpu").manual_seed(B * 7 + H * 13 + Nq + Nk * 3 + D)

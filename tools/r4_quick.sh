@@ -1,19 +1,17 @@
 #!/bin/bash
-# Rebuild only the named units of libtfa_hip.so (default: the four D=128 forward units + tfa_api) with the Makefile's flags and audit, relink with the
-# objects already in build/.  For kernel-header edits that cannot change the other units (x4 / backward / 64-wide): `make` would rebuild all of them.
-# usage: tools/r4_quick.sh [unit ...]      e.g. tools/r4_quick.sh tfa_fwd_inst_bf16_128_c1 tfa_api
+# Round-4 arms library: lib_x/libtfa_hip.so = the product objects of build/ with the bf16 D=128 forward units, tfa_api and the ablation unit rebuilt
+# with -DTFA_R4_ARMS (the A/B arms 38.. of tfa_launch.h) — about a minute, the product library in lib/ is not touched.
+#   tools/r4_quick.sh            then   TFA_LIB=$PWD/tiny-flash-attention_amd/lib_x/libtfa_hip.so python tools/ab_variants.py --variants 30,61 ...
 set -e
 cd "$(dirname "$0")/../tiny-flash-attention_amd/csrc"
-UNITS=${@:-"tfa_fwd_inst_bf16_128_c1 tfa_fwd_inst_bf16_128_c0 tfa_fwd_inst_f16_128_c1 tfa_fwd_inst_f16_128_c0 tfa_api"}
-for u in $UNITS; do
-  touch $u.hip
-  make -o tfa_fwd_kernel_il.h ../build/$u.o > /tmp/r4_quick_$u.log 2>&1 &
+mkdir -p ../build_x ../lib_x
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -I../../experiments/csrc -Wno-unused-function -Wno-inline-asm -Wno-unused-variable -fno-gpu-rdc -mllvm -amdgpu-early-inline-all=true -DTFA_R4_ARMS"
+for u in tfa_fwd_inst_bf16_128_c1 tfa_fwd_inst_bf16_128_c0 tfa_api; do
+  ( /opt/rocm/bin/hipcc $FLAGS -c $u.hip -o ../build_x/$u.o > /tmp/r4x_$u.log 2>&1 || echo "FAILED $u" ) &
 done
+( /opt/rocm/bin/hipcc $FLAGS -c ../../experiments/csrc/tfa_ilab_inst_bf16_128.hip -o ../build_x/tfa_ilab_inst_bf16_128.o > /tmp/r4x_ilab.log 2>&1 || echo "FAILED ilab" ) &
 wait
-for u in $UNITS; do tail -2 /tmp/r4_quick_$u.log | grep -v warning || true; done
-for u in $UNITS; do [ -f ../build/$u.o ] || { echo "BUILD FAILED: $u (see /tmp/r4_quick_$u.log)"; tail -5 /tmp/r4_quick_$u.log; exit 1; }; done
-objs=$(ls ../build/*.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../lib/libtfa_hip.so
-# mark everything else up to date so that a later plain `make` does not rebuild the untouched units
-touch ../build/*.o ../lib/libtfa_hip.so
-echo "relinked ../lib/libtfa_hip.so"
+for u in tfa_fwd_inst_bf16_128_c1 tfa_fwd_inst_bf16_128_c0 tfa_api tfa_ilab_inst_bf16_128; do [ -f ../build_x/$u.o ] || { echo "BUILD FAILED: $u"; tail -5 /tmp/r4x_*.log; exit 1; }; done
+objs=$(ls ../build/*.o | grep -v "tfa_fwd_inst_bf16_128_c[01].o\|tfa_api.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs ../build_x/*.o -o ../lib_x/libtfa_hip.so
+echo "built lib_x/libtfa_hip.so"
