@@ -16,8 +16,8 @@
 // Host glue only: CHECK_INPUT (include/attention_api.cuh:12-18), allocation of the results (flash_attention.cu:756-759) and
 // one call into libtfa_hip.so on the current stream.  Unlike the reference it does not cudaDeviceSynchronize() and turns
 // errors into exceptions instead of exit(1) (:767-769).  Deliberate differences, all loud:
-// tensors must live on the GPU and be fp16 or bf16 — attention_cuda's fp32/fp64 dispatch and _kernels' CPU fp32 tensors
-// are rejected with a TORCH_CHECK naming the fix, never silently down-cast or computed on the CPU.
+// tensors must live on the GPU (the _kernels module's CPU tensors are rejected with a TORCH_CHECK naming the fix: there is no CPU path)
+// and be fp16, bf16 or fp32 (fp32 = the reference's own fixtures, served by the fp32 correctness kernel tfa_fwd_f32.hip; fp64 is rejected).
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/core/DeviceGuard.h>
 #include <torch/extension.h>
@@ -41,12 +41,15 @@
 
 namespace {
 
+// fp16 / bf16: the MFMA kernels.  fp32 (the reference's own fixtures: flash_attention_c/test.py:35-48 torch.rand fp32, and the float arm of
+// flash_attention_cuda/csrc/flash_attention.cu:411): the fp32 correctness path of libtfa_hip.so, fp32 arithmetic end to end — nothing is
+// down-cast.  fp64 (the double arm of :411) is rejected loudly.
 int dtype_code(const torch::Tensor& q, const torch::Tensor& k, const torch::Tensor& v, const char* who) {
-  TORCH_CHECK(q.scalar_type() == torch::kFloat16 || q.scalar_type() == torch::kBFloat16, who,
-              ": q, k, v must be float16 or bfloat16 on this GPU path (got ", q.scalar_type(),
-              "); cast with .half() or .bfloat16() — nothing is down-cast silently");
+  TORCH_CHECK(q.scalar_type() == torch::kFloat16 || q.scalar_type() == torch::kBFloat16 || q.scalar_type() == torch::kFloat32, who,
+              ": q, k, v must be float16, bfloat16 or float32 on this GPU path (got ", q.scalar_type(),
+              "); cast with .float(), .half() or .bfloat16() — nothing is down-cast silently");
   TORCH_CHECK(k.scalar_type() == q.scalar_type() && v.scalar_type() == q.scalar_type(), who, ": q, k, v must share a dtype");
-  return q.scalar_type() == torch::kBFloat16 ? TFA_BF16 : TFA_F16;
+  return q.scalar_type() == torch::kBFloat16 ? TFA_BF16 : q.scalar_type() == torch::kFloat32 ? TFA_F32 : TFA_F16;
 }
 
 void* current_stream(const torch::Tensor& q) {
@@ -65,6 +68,10 @@ int run_forward(const torch::Tensor& q, const torch::Tensor& k, const torch::Ten
   int64_t* st[4] = {p.q_stride, p.k_stride, p.v_stride, p.o_stride};
   for (int i = 0; i < 4; ++i) { st[i][0] = ts[i]->stride(0); st[i][1] = ts[i]->stride(1); st[i][2] = ts[i]->stride(2); }
   p.softmax_scale = softmax_scale; p.is_causal = is_causal ? 1 : 0; p.dtype = dtype; p.out_dtype = dtype;
+  if (dtype == TFA_F32) {                                   // 16-byte aligned rows are all the fp32 path asks of the strides
+    TORCH_CHECK(q.size(3) % 4 == 0, "fp32 tensors: the head dimension must be a multiple of 4");
+    return tfa_fwd(&p, current_stream(q));
+  }
   const int splits = out.is_contiguous() ? tfa_fwd_suggest_splits(&p) : 1;
   if (splits > 1) {
     const long long need = tfa_fwd_splitkv_workspace(&p, splits);

@@ -12,6 +12,8 @@
 #include "tfa_launch.h"
 
 namespace tfa {
+// fp32 tensors (the reference's fp32 fixtures: a correctness path on v_mfma_f32_32x32x2_f32): tfa_fwd_f32.hip
+hipError_t launch_f32(const KArgs& a, bool causal, hipStream_t stream, int* grid_out, bool dry);
 template <> hipError_t launch_splitkv_wide<__bf16>(const KArgs&, bool, hipStream_t, LaunchGeom*, bool);
 template <> hipError_t launch_splitkv_wide<_Float16>(const KArgs&, bool, hipStream_t, LaunchGeom*, bool);
 }  // namespace tfa
@@ -196,7 +198,52 @@ bool pack_gqa_rows(const tfa_fwd_params* p, tfa_fwd_params* o, int* row_mod = nu
   return true;
 }
 
+// fp32 q, k, v (tfa_fwd_params::dtype == TFA_F32): the correctness path behind the reference's fp32 fixtures (tfa_fwd_f32.hip).  fp32 output
+// only; any strides with 16-byte aligned rows; head dims = multiples of 4 up to 256; GQA, Nq != Nk, kv_offset / nk_total as for the 16-bit types.
+int run_f32(const tfa_fwd_params* p, void* stream, tfa::LaunchGeom* geom, bool dry) {
+  if (!p->q || !p->k || !p->v || !p->out) return TFA_ERR_NULL;
+  if (p->out_dtype != TFA_F32) return TFA_ERR_DTYPE;
+  if (p->D < 4 || p->D > 256 || (p->D % 4) != 0) return TFA_ERR_HEAD_DIM;
+  if (p->B <= 0 || p->H <= 0 || p->Hk <= 0 || p->Nq <= 0 || p->Nk <= 0 || p->H % p->Hk != 0) return TFA_ERR_SHAPE;
+  if (!(p->softmax_scale > 0.f) || !isfinite(p->softmax_scale)) return TFA_ERR_SCALE;
+  if (p->flags != 0 || p->reserved_ != 0) return TFA_ERR_SHAPE;          // (TFA_FWD_EXACT_MAX is about 16-bit rounding points: this path has none)
+  const int64_t* st[4] = {p->q_stride, p->k_stride, p->v_stride, p->o_stride};
+  for (int t = 0; t < 4; ++t) {
+    for (int i = 0; i < 3; ++i)
+      if (st[t][i] < 0 || (st[t][i] * 4) % 16 != 0) return TFA_ERR_STRIDE;
+    if (st[t][2] < p->D) return TFA_ERR_STRIDE;
+  }
+  if (((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->out) & 15) return TFA_ERR_ALIGN;
+  if (p->lse && ((uintptr_t)p->lse & 3)) return TFA_ERR_ALIGN;
+  tfa::KArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = p->q; a.k = p->k; a.v = p->v; a.o = p->out; a.lse = p->lse;
+  a.B = p->B; a.H = p->H; a.Hk = p->Hk; a.Nq = p->Nq; a.Nk = p->Nk;
+  if (p->kv_offset < 0 || p->nk_total < 0) return TFA_ERR_SHAPE;
+  const int64_t total = p->nk_total ? p->nk_total : (p->kv_offset + p->Nk);
+  if (p->kv_offset + p->Nk > total || total - p->Nq - p->kv_offset < -(int64_t)0x3fffffff || total >= (int64_t)0x3fffffff) return TFA_ERR_SHAPE;
+  a.shift = (int)(total - p->Nq - p->kv_offset);
+  a.qs_b = p->q_stride[0]; a.qs_h = p->q_stride[1]; a.qs_n = p->q_stride[2];
+  a.ks_b = p->k_stride[0]; a.ks_h = p->k_stride[1]; a.ks_n = p->k_stride[2];
+  a.vs_b = p->v_stride[0]; a.vs_h = p->v_stride[1]; a.vs_n = p->v_stride[2];
+  a.os_b = p->o_stride[0]; a.os_h = p->o_stride[1]; a.os_n = p->o_stride[2];
+  a.scale = p->softmax_scale;
+  a.scale_log2 = p->softmax_scale * 1.4426950408889634f;
+  const int64_t nbh = (int64_t)p->B * p->H;
+  if (nbh * ((p->Nq + 31) / 32) >= (int64_t)0x7fffffff) return TFA_ERR_SHAPE;
+  a.nbh = (int)nbh;
+  a.dv = p->D;
+  int grid = 0;
+  const hipError_t e = tfa::launch_f32(a, p->is_causal != 0, reinterpret_cast<hipStream_t>(stream), &grid, dry);
+  if (geom) { geom->grid = grid; geom->block = 256; geom->lds = 0; }
+  return (int)e;
+}
+
 int run(const tfa_fwd_params* p_in, void* stream, tfa::LaunchGeom* geom, bool dry, int* variant_out = nullptr) {
+  if (p_in && p_in->dtype == TFA_F32) {
+    if (variant_out) *variant_out = -1;
+    return run_f32(p_in, stream, geom, dry);
+  }
   tfa_fwd_params packed;
   int row_mod = 0;
   const bool may_pack = g_variant < 0 && !(g_dbg_flags & 4096) && p_in && !(p_in->flags & TFA_FWD_EXACT_MAX);
@@ -454,6 +501,7 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
 
 int tfa_fwd_suggest_splits(const tfa_fwd_params* p_in) {
   if (!p_in || g_variant >= 0) return 1;                  // a forced kernel variant means: run exactly that
+  if (p_in->dtype == TFA_F32) return 1;                   // (the fp32 correctness path is one pass)
   if (p_in->flags & TFA_FWD_EXACT_MAX) return 1;          // (the merge of partial passes moves the rounding points as well)
   tfa_fwd_params packed;
   const tfa_fwd_params* p = pack_gqa_rows(p_in, &packed) ? &packed : p_in;

@@ -12,6 +12,8 @@ import torch
 from . import _lib
 
 _DT = {torch.float16: _lib.TFA_F16, torch.bfloat16: _lib.TFA_BF16}
+_DT_IN = dict(_DT)
+_DT_IN[torch.float32] = _lib.TFA_F32    # fp32 q,k,v: the fp32 correctness path (the reference's fp32 fixtures; tfa_fwd_f32.hip) — forward only
 
 
 def _check_input(x, name):
@@ -48,8 +50,10 @@ def flash_attn_fwd(q, k, v, is_causal=False, softmax_scale=None, *, layout="bhnd
             raise RuntimeError(f"{n} must be 4-D")
         if t.stride(3) != 1:
             raise RuntimeError(f"{n} must have unit stride along the head dimension")
-    if q.dtype not in _DT or k.dtype != q.dtype or v.dtype != q.dtype:
-        raise TypeError(f"q,k,v must share dtype float16 or bfloat16 (got {q.dtype}, {k.dtype}, {v.dtype})")
+    if q.dtype not in _DT_IN or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise TypeError(f"q,k,v must share dtype float16, bfloat16 or float32 (got {q.dtype}, {k.dtype}, {v.dtype})")
+    if q.dtype == torch.float32 and (exact_max or (out is not None and out.dtype != torch.float32)):
+        raise TypeError("float32 q,k,v: the fp32 correctness path returns float32 and has no 16-bit rounding points (exact_max does not apply)")
     if k.device != q.device or v.device != q.device:
         raise RuntimeError("q,k,v must be on the same device")
     if layout == "bhnd":
@@ -86,7 +90,7 @@ def flash_attn_fwd(q, k, v, is_causal=False, softmax_scale=None, *, layout="bhnd
         arr[0], arr[1], arr[2] = s
     p.softmax_scale = float(softmax_scale)
     p.is_causal = 1 if is_causal else 0
-    p.dtype = _DT[q.dtype]
+    p.dtype = _DT_IN[q.dtype]
     p.out_dtype = _lib.TFA_F32 if out.dtype == torch.float32 else _DT[out.dtype]
     p.kv_offset = int(kv_offset)                     # split-KV: k, v are keys [kv_offset, kv_offset+Nk) of nk_total
     p.nk_total = 0 if nk_total is None else int(nk_total)
@@ -304,7 +308,8 @@ def flash_attn(q, k, v, is_causal, softmax_scale):
     """``_kernels.flash_attn(q, k, v, is_causal, softmax_scale) -> out``
     (flash_attention_c/csrc/attn.cpp:237-262).  Same math as the CPU sibling, including its
     bottom-right-aligned causal mask for Nq != Nk (attn.cpp:121-124) and strided inputs
-    (attn.cpp:171-203); tensors live on the GPU and are 16-bit here."""
+    (attn.cpp:171-203); tensors live on the GPU: fp16 / bf16 (the MFMA kernels) or fp32 (the reference's own fixture dtype: the fp32
+    correctness path, fp32 arithmetic end to end)."""
     out, _ = flash_attn_fwd(q, k, v, bool(is_causal), float(softmax_scale), return_lse=False, auto_split=True)
     return out
 
