@@ -228,31 +228,37 @@ def workload_text(cfg_name, world, bwd=False, bwd_form="default"):
             f"q/k/v normal(0,0.5) resident in HBM, scale=1/sqrt(D)")
 
 
-def library_sha256():
+# the sources that define what the headline kernel executes: a change to any of them makes a recorded HBM-traffic figure stale
+KERNEL_SOURCES = ["tfa_fwd_kernel.h", "tfa_fwd_kernel_dma.h", "tfa_fwd_kernel_il.h", "tfa_fwd_il_regs.h", "tfa_fwd_il_pass_prologue.inc",
+                  "tfa_fwd_il_tile_loop.inc", "tfa_fwd_il_epilogue.inc", "tfa_fwd_inst.inc", "tfa_launch.h", "tfa_api.hip", "Makefile"]
+
+
+def kernel_sources_sha256():
+    """SHA-256 over the forward kernel's sources (csrc/: KERNEL_SOURCES, in that order).  (Not over libtfa_hip.so: hipcc's objects are not
+    bit-reproducible, so a rebuild of unchanged sources would look like a new kernel.)"""
     import hashlib
-    from tiny_flash_attention_amd import _lib
     h = hashlib.sha256()
-    with open(_lib.LIB_PATH, "rb") as f:
-        for blk in iter(lambda: f.read(1 << 20), b""):
-            h.update(blk)
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "tiny-flash-attention_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
     return h.hexdigest()
 
 
 def hbm_traffic_for(cfg_name, variant, bwd):
     """HBM bytes per launch of the dominant kernel: NOT measured in this run (PMC passes perturb timing and run separately:
     tools/prof_pmc.py -> tools/update_hbm_traffic.py -> profiles/hbm_traffic.json).  Every entry is stamped with the SHA-256 of the
-    libtfa_hip.so it was measured on; a different library (a kernel changed since) gives traffic = null and says why."""
+    kernel sources it was measured on (and the git head); sources that changed since give traffic = null and say why."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
         if variant >= 0 or bwd or cfg_name not in tj:
             return None, None
         e = tj[cfg_name]
-        have = library_sha256()
-        if e.get("library_sha256") != have:
-            return None, (f"stale: profiles/hbm_traffic.json[{cfg_name}] was measured on library {str(e.get('library_sha256'))[:12]} "
-                          f"({e.get('git_head', '?')}), this run loaded {have[:12]} — re-run tools/prof_pmc.py + tools/update_hbm_traffic.py")
+        have = kernel_sources_sha256()
+        if e.get("kernel_sources_sha256") != have:
+            return None, (f"stale: profiles/hbm_traffic.json[{cfg_name}] was measured on kernel sources {str(e.get('kernel_sources_sha256'))[:12]} "
+                          f"({e.get('git_head', '?')}), this tree has {have[:12]} — re-run tools/prof_pmc.py + tools/update_hbm_traffic.py")
         return e["bytes"], ("static: profiles/hbm_traffic.json (" + e.get("source", "rocprofv3 --pmc passes of this command") +
-                            f"), measured on this very library ({have[:12]}, {e.get('git_head', '?')}), not in this run")
+                            f"), measured on these very kernel sources ({have[:12]}, {e.get('git_head', '?')}), not in this run")
     except Exception as ex:
         return None, f"unavailable: {ex!r}"
 

@@ -57,10 +57,11 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 105 /* 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
+#define TFA_VERSION 106 /* 0.1.6: + fp32 q,k,v (TFA_F32 input: the correctness path behind the reference's fp32 fixtures), variant numbers are ids (tfa_variant_available), tfa_bwd_workspace_bytes is 0 wherever the workspace would be ignored; 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
 
 /* element types */
-enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1, TFA_F32 = 2 /* output only */ };
+enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1,
+                 TFA_F32 = 2 /* outputs of the 16-bit kernels; as the dtype of q,k,v: the fp32 correctness path (below) */ };
 
 enum tfa_status {
   TFA_OK = 0,
@@ -98,7 +99,12 @@ typedef struct tfa_fwd_params {
   int64_t o_stride[3];   /* in elements of out_dtype */
   float softmax_scale;
   int32_t is_causal;     /* bottom-right aligned when Nq != Nk */
-  int32_t dtype;         /* tfa_dtype of q,k,v: TFA_F16 or TFA_BF16 */
+  int32_t dtype;         /* tfa_dtype of q,k,v: TFA_F16 or TFA_BF16 (the MFMA kernels: everything this header describes), or TFA_F32 — fp32
+                          * tensors, the dtype of the reference's own CPU fixtures (flash_attention_c/test.py:35-48) and of the float arm of
+                          * flash_attention_cuda/csrc/flash_attention.cu:411: served by a correctness kernel with fp32 arithmetic end to end
+                          * (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate; csrc/tfa_fwd_f32.hip), out_dtype must be TFA_F32, head dims =
+                          * multiples of 4 up to 256, rows 16-byte aligned, flags 0; tfa_fwd only (no split-KV, no backward).  Meets the
+                          * reference's fp32 results to 1e-5 (tests/test_f32_gpu.py). */
   int32_t out_dtype;     /* == dtype, or TFA_F32 (debug/parity: unrounded fp32 O; also the partial results of split-KV) */
   /* split-KV: when k, v are the chunk [kv_offset, kv_offset + Nk) of a longer key
    * sequence of nk_total keys, the causal mask is taken against GLOBAL key positions: key kv_offset + j is

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"include/tfa.h declares {n} but libtfa_hip.so does not export it"
     assert sorted(_lib.SYMBOLS) == names
-    assert L.tfa_version() == 105
+    assert L.tfa_version() == 106
 
 
 def _params(B=2, H=4, Hk=4, Nq=128, Nk=128, D=128, dtype=_lib.TFA_BF16, out_dtype=None, scale=0.1, base=0x10000):
@@ -100,10 +100,14 @@ def test_product_build_rejects_ab_arms():
 def test_rejects_bad_descriptors():
     cases = []
     p = _params(); p.q = None; cases.append((p, -1))
-    cases.append((_params(dtype=2), -2))
+    cases.append((_params(dtype=2, out_dtype=1), -2))  # fp32 q,k,v (the correctness path) return fp32 only
+    cases.append((_params(dtype=3), -2))               # no such dtype
+    cases.append((_params(dtype=2, D=6), -3))          # fp32 path: head dims are multiples of 4
     cases.append((_params(out_dtype=0), -2))           # bf16 in, f16 out
     cases.append((_params(D=100), -3))                 # not a multiple of 8
     cases.append((_params(D=264), -3))                 # beyond the widest kernel
+    st, grid, block, lds = plan(_params(dtype=2, B=2, H=4, Hk=2, Nq=100, Nk=333, D=72))   # fp32 tensors: one wave per 32 query rows, four waves per workgroup
+    assert (st, grid, block, lds) == (0, (2 * 4 * 4 + 3) // 4, 256, 0)
     assert plan(_params(D=96))[0] == 0 and plan(_params(D=32, dtype=_lib.TFA_F16))[0] == 0 and plan(_params(D=8))[0] == 0
     st, grid, block, lds = plan(_params(B=2, H=4, Hk=4, Nq=1024, Nk=1024, D=256))   # x4-d256: 128-row blocks paired, five 32 KiB tile buffers
     assert st == 0 and block == 256 and grid == 2 * 4 * 4 and lds == 5 * 64 * 256 * 2

@@ -221,3 +221,23 @@ def test_bench_one_rank_keeps_the_headline_config():
 def test_bench_self_spawns_its_ranks_outside_torchrun():
     line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--fake-step-ms", "5", "--no-gather"], 1)
     assert line["n_gpus"] == 2 and "gather" not in line and line["config"]["global_batch"] == 16
+
+
+def test_bench_quotes_hbm_traffic_only_for_the_kernel_sources_it_was_measured_on(monkeypatch):
+    """roofline.traffic comes from profiles/hbm_traffic.json, stamped with the SHA-256 of the forward kernel's sources at measurement time
+    (tools/update_hbm_traffic.py): a tree whose kernel sources differ gets null and the reason, never a figure measured on another kernel."""
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    entry = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["cfg3"]
+    assert len(entry["kernel_sources_sha256"]) == 64 and entry["bytes"] > 5.39e8          # at least the algorithmic bytes
+    monkeypatch.setattr(bench, "kernel_sources_sha256", lambda: entry["kernel_sources_sha256"])
+    traffic, src = bench.hbm_traffic_for("cfg3", -1, False)
+    assert traffic == entry["bytes"] and src.startswith("static")
+    monkeypatch.setattr(bench, "kernel_sources_sha256", lambda: "0" * 64)
+    traffic, src = bench.hbm_traffic_for("cfg3", -1, False)
+    assert traffic is None and src.startswith("stale")
+    assert bench.hbm_traffic_for("cfg3", 30, False) == (None, None)                    # a forced kernel variant: not the measured kernel

@@ -410,7 +410,9 @@ def test_reference_operator_signatures(tfa, oracle, dev):
     with pytest.raises(RuntimeError, match="must be contiguous"):
         tfa.flash_attention_v2_cutlass(qd.transpose(1, 2), kd, vd, True, 0.125)
     with pytest.raises(TypeError):
-        tfa.flash_attention_v2_cutlass(qd.float(), kd.float(), vd.float(), True, 0.125)
+        tfa.flash_attention_v2_cutlass(qd.double(), kd.double(), vd.double(), True, 0.125)     # fp64: rejected (fp32 runs the fp32 correctness path: tests/test_f32_gpu.py)
+    o32, l32 = tfa.flash_attention_v2_cutlass(qd.float(), kd.float(), vd.float(), True, 0.125)
+    assert o32.dtype == torch.float32 and (o32.cpu() - oracle.exact64(q, k, v, True, 0.125)).abs().max().item() <= 2e-5
 
 
 def test_inputs_not_modified_and_deterministic(tfa, oracle, dev):
@@ -952,8 +954,10 @@ def test_dropin_extension_module_attention_cuda(tfa, oracle, dev):
     assert (out2.float().cpu() - ref2).abs().max().item() <= 2e-3
     with pytest.raises(RuntimeError, match="q must be a CUDA tensor"):
         flash_attention_v2_cuda(q, k, v)
-    with pytest.raises(RuntimeError, match="must be float16 or bfloat16"):
-        flash_attention_v2_cuda(qd.float(), kd.float(), vd.float())            # the reference dispatches fp32/fp64 too; here: loud, never down-cast
+    with pytest.raises(RuntimeError, match="must be float16, bfloat16 or float32"):
+        flash_attention_v2_cuda(qd.double(), kd.double(), vd.double())         # the reference dispatches fp64 too; here: loud, never down-cast
+    o32 = flash_attention_v2_cuda(qd.float(), kd.float(), vd.float())          # its float arm (flash_attention.cu:411): the fp32 correctness path, fp32 out
+    assert o32.dtype == torch.float32 and (o32.cpu() - oracle.exact64(q, k, v, False, 1.0 / math.sqrt(q.shape[-1]))).abs().max().item() <= 2e-5
     with pytest.raises(TypeError):
         flash_attention_v2_cuda(qd, kd, vd, True, 0.1)
 

@@ -307,7 +307,7 @@ const char* tfa_strerror(int status) {
   switch (status) {
     case TFA_OK: return "success";
     case TFA_ERR_NULL: return "tfa: a required pointer is NULL";
-    case TFA_ERR_DTYPE: return "tfa: unsupported dtype (q/k/v must be fp16 or bf16; out must match or be fp32)";
+    case TFA_ERR_DTYPE: return "tfa: unsupported dtype (q/k/v must be fp16 or bf16, out matching or fp32; or q/k/v fp32 with fp32 out: the correctness path)";
     case TFA_ERR_HEAD_DIM: return "tfa: unsupported head dim (forward, split-KV and backward: multiples of 8 up to 256; TFA_FWD_EXACT_MAX: multiples of 8 up to 128; merge: multiples of 4 up to 256)";
     case TFA_ERR_SHAPE: return "tfa: bad shape (sizes must be positive and H % Hk == 0)";
     case TFA_ERR_STRIDE: return "tfa: bad stride (must be >=0, rows 16-byte aligned and non-overlapping; 768 rows of a (b,h) slice must span < 2 GiB, the whole slice for split-KV / backward)";
