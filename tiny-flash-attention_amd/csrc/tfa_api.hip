@@ -267,12 +267,6 @@ int run(const tfa_fwd_params* p_in, void* stream, tfa::LaunchGeom* geom, bool dr
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipError_t e;
   const bool wide = p->D > 64;   // kernel width: 64 serves D <= 64, 128 serves 64 < D <= 128, 256 the rest (KArgs::dv = the valid part)
-#if defined(TFA_EXPERIMENTAL) || defined(TFA_R4_ARMS)
-  if (variant >= 55 && variant <= 60) {                  // round-4 timing-only ablations (bf16, D = 128, 16-bit out)
-    if (p->dtype != TFA_BF16 || p->D != 128 || f32out) return TFA_ERR_VARIANT;
-    return (int)tfa::launch_il_ablation(a, variant, causal, s, geom, dry);
-  }
-#endif
   if (p->D > 128) {
     e = (p->dtype == TFA_BF16) ? tfa::launch_x4_unit<__bf16, 256>(a, causal, f32out, 0, s, geom, dry)
                                : tfa::launch_x4_unit<_Float16, 256>(a, causal, f32out, 0, s, geom, dry);

@@ -1,5 +1,4 @@
 // one instantiation unit: dtype=f16 head_dim=128 causal=0
-#define TFA_F16_UNIT 1   // (debug-only arms are instantiated in the bf16 units)
 #define TFA_T _Float16
 #define TFA_D 128
 #define TFA_CAUSAL false

@@ -1,5 +1,4 @@
 // one instantiation unit: dtype=f16 head_dim=64 causal=1
-#define TFA_F16_UNIT 1   // (debug-only arms are instantiated in the bf16 units)
 #define TFA_T _Float16
 #define TFA_D 64
 #define TFA_CAUSAL true

@@ -52,23 +52,10 @@ constexpr int IL_OSTORE_AUX = 2;         // cache policy of the O row stores: nt
                                          // the K/V tiles every query block of the head re-reads (cfg3: +1.8 %, others +-0; profiles/r02_ostore_ab.txt)
 constexpr int VF_IL_WINDOWED = 1 << 24;  // K/V tiles through per-tile descriptors (rsrc_at): a (b,h) slice may exceed 2 GiB.  ~6 % slower (a fresh
                                          // descriptor per tile: ~14 SALU + the SGPR->VMEM wait states), so only launched when needed
-constexpr int VF_IL_TAIL = 1 << 28;      // a wave's LAST tile (no S(j+1) to compute) runs a pinned body of its own — the softmax of P slot s+1 behind the PV MFMAs of
-                                         // slot s — instead of the burst-structured slow path.  Every step of a causal diagonal has two waves on their last tile
-constexpr int VF_IL_PREF2 = 1 << 29;     // paired causal blocks: the light pass's K(0)/V(0)/K(1)/Q are requested before the heavy pass's epilogue (as VF_IL_PREF) AND
-                                         // the light prologue waits with a COUNTED vmcnt, so that it does not also wait for the heavy pass's O stores to retire
-constexpr int VF_IL_ITERTRACE = 1 << 30;  // debug instantiation: every wave of the first workgroups stamps the end of every iteration (before the wait, after
-                                         // the wait, after the barrier) into the idle epilogue region and copies the records out behind each pass (tools/trace_iters.py)
-constexpr int IL_ITR_WGS = 64, IL_ITR_RECS = 256;   // traced workgroups (the first of the grid), records per wave
-constexpr int VF_IL_PF4 = 1, VF_IL_PF6 = 2;   // (A/B arms; the bits are VF_TRREAD / VF_NOSKIP, which mean nothing to this kernel) LDS fragment read-ahead of 4 / 6 MFMAs instead of 2
-// round-4 A/B arms on bits that mean nothing to this kernel (VF_KPRE, VF_VPRE, VF_PP, ping-pong bits 8..9):
-constexpr int VF_IL_PRIOALT8 = 8, VF_IL_PRIOALT4 = 16;   // the two waves of a SIMD take turns at s_setprio 1, every 8 / 4 MFMA slots: age-based arbitration lets the older
-                                                         // wave run ahead and the younger finish the tile alone (a quarter of every iteration at one wave's efficiency)
-constexpr int VF_IL_DMALOW = 32;                         // waves 0..NW/2-1 (the older of every SIMD) issue ALL LDS-DMA pieces: the arbitration losers carry less
-constexpr int VF_IL_LIGHTFIRST = 512;                    // causal pairs: the LIGHT block first, then the heavy one.  Heavy-first, the eight workgroups of a head stream
-                                                         // the head's tiles in lockstep and then re-read tiles 0.. for their light passes long after the L2 dropped them
-                                                         // (the light passes are a quarter of all tile reads: the L2 hit rate of 0.73); light-first, the heavy passes
-                                                         // follow each other four tiles apart behind tiles a light pass has just fetched
-constexpr int VF_IL_PRIOHI = 256;                        // static s_setprio 1 for waves NW/2.. (the younger of every SIMD)
+constexpr int VF_IL_PREF2 = 1 << 29;     // paired causal blocks: the light pass's K(0)/V(0)/K(1)/Q are requested behind the heavy pass's tile loop, in FRONT of
+                                         // its O stores, and waited for with a COUNTED vmcnt behind them — vmcnt retires in issue order, so the light prologue
+                                         // never waits for the stores' write acknowledges (round 4: light prologue 6.9 k -> 3.1 k cycles, +0.8 % on the headline;
+                                         // earlier requests — inside the loop — cost the loop more registers than they save: docs/LABLOG.md L-9)
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
                                          // so the two waves of a SIMD never sit in an LDS-DMA issue stall at the same time
 
@@ -96,8 +83,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   constexpr int CPR = D / 8;
   constexpr int TILE_BYTES = BN * D * 2;
   constexpr int PIECES = TILE_BYTES / 1024;
-  constexpr bool DMALOW = (VF & VF_IL_DMALOW) != 0;
-  constexpr int PPW = PIECES / NWG * (DMALOW ? 2 : 1);   // DMA pieces per (issuing) wave per tensor per tile
+  constexpr int PPW = PIECES / NWG;                // DMA pieces per wave per tensor per tile
   static_assert(DVB >= 1 && DVB <= D / 32, "valid 32-column blocks of a D-wide kernel");
   constexpr int DS = 2 * DVB;                      // k-slots that are multiplied
   constexpr int DT = DVB;                          // 32-column tiles of O that exist
@@ -107,7 +93,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   // (settled by same-process A/Bs, all within +-0.7 %: read-ahead 3 or 4, 19 or 24 elements in part 1, a uniform element-to-slot
   //  map, inline-asm QK^T MFMAs, one key block after the other in part 1, the causal wave permutation — profiles/r02_*_ab.txt)
   constexpr int NE1 = 21;                          // softmax elements (of 32 per lane) summed/packed during part 1
-  constexpr int PFK = (VF & VF_IL_PF6) ? 6 : (VF & VF_IL_PF4) ? 4 : 2, PFV = PFK;   // fragment read-ahead, in MFMAs
+  constexpr int PFK = 2, PFV = 2;                  // fragment read-ahead, in MFMAs
   // MFMA slot (0..N1+N2-1) in which softmax element e (0..31) is summed and packed; its exp2 is issued one slot and its
   // scale/subtract two slots earlier.  P slot s (elements 8s..8s+7) feeds PV MFMAs N1+DT*s.., so it must be packed in
   // an EARLIER slot than N1+DT*s (also the distance the asm MFMA needs after a VALU write of its operand).
@@ -120,9 +106,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #define KT(i) ((i) & 1)
 #define KS(i) ((i) >> 1)
   constexpr bool PAIR = CAUSAL && (VF & VF_PAIR);
-  static_assert(PPW >= 1 && PPW * NWG == PIECES * (DMALOW ? 2 : 1), "tile does not split into whole DMA pieces per wave");
-  static_assert(!DMALOW || !(VF & (VF_IL_KSPLIT | VF_IL_DMASTAGGER | VF_IL_SEAM)), "DMALOW: plain il8 / il4 only");
-  constexpr int PRIO_PER = (VF & VF_IL_PRIOALT8) ? 8 : (VF & VF_IL_PRIOALT4) ? 4 : 0;
+  static_assert(PPW >= 1 && PPW * NWG == PIECES, "tile does not split into whole DMA pieces per wave");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -139,9 +123,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const int wave = KSPLIT ? wave_id % NWG : wave_id;   // index inside the query block: rows, DMA pieces, epilogue slice
   // the 32-row block of a wave (a permutation that evens out the diagonal block's tiles per SIMD — {0,1,2,3,7,6,5,4} — measured
   // neutral: the per-tile barrier sets the diagonal's wall time whatever the map; profiles/r02_window_ab2.txt)
-  // (ITERTRACE builds, debug flag 2048: the upper and the lower four waves swap their rows — which of a SIMD's two waves is the lone
-  //  one when half a block is idle: tools/r4_lone.py)
-  const int wrow = ((VF & VF_IL_ITERTRACE) && (p.dbg & 2048)) ? (wave ^ (NW / 2)) : wave;
+  const int wrow = wave;
   const int qi = lane & 31;
   const int hi = lane >> 5;
 
@@ -211,26 +193,12 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   // (query heads that share a K/V head share its tiles in L2: no streaming hint then; nor for a K/V cache that the 256 MB memory-side
   //  cache can keep until the next decode step — the host sets KArgs::kv_stream from 768 MiB on: profiles/r03_decode_nt_ab.txt)
   const bool kv_private = p.H == p.Hk && p.kv_stream != 0;
-  const bool upper_wave = wave_id >= NW / 2;
-  const bool dma_wave = !DMALOW || !upper_wave;
-  if ((VF & VF_IL_PRIOHI) && upper_wave) __builtin_amdgcn_s_setprio(1);
-  // PRIOALT: at MFMA slot g (a multiple of the period) the wave whose turn it is raises its priority, its SIMD partner drops it
-  auto prio_at = [&](int g) {
-    if constexpr (PRIO_PER > 0) {
-      if (g % PRIO_PER == 0) {
-        if ((((g / PRIO_PER) & 1) != 0) == upper_wave) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-      }
-    }
-  };
   auto dma_k1 = [&](int t, int buf, int i) {
-    if (DMALOW && !dma_wave) return;
     if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(kbase, k_bytes, (unsigned long long)t * (unsigned)k_tile_stride), lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i]);
     else if ((VF & VF_IL_IDLE) && IL_DECODE_NT && kv_private) lds_dma16_m0_nt(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
     else lds_dma16_m0(k_rs, lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i] + t * k_tile_stride);
   };
   auto dma_v1 = [&](int t, int buf, int i) {
-    if (DMALOW && !dma_wave) return;
     if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(vbase, v_bytes, (unsigned long long)t * (unsigned)v_tile_stride), lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i]);
     else if ((VF & VF_IL_IDLE) && IL_DECODE_NT && kv_private) lds_dma16_m0_nt(v_rs, lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i] + t * v_tile_stride);
     else lds_dma16_m0(v_rs, lds_base + (2 + buf) * TILE_BYTES + (wave * PPW + i) * 1024, v_src[i] + t * v_tile_stride);
@@ -269,7 +237,6 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   auto own_tiles = [&](int ntg) -> int { return KSPLIT ? (ntg - grp + 1) >> 1 : ntg; };   // this wave's share of ntg tiles of the head
   auto key0_of = [&](int t) -> int { return (KSTEP * t + grp) * BN; };                        // first key of the wave's tile t
   auto block_of = [&](int pass) -> int {
-    if (PAIR && (VF & VF_IL_LIGHTFIRST)) return (pass == 0 && (p.nmb - 1 - wi) != wi) ? wi : (p.nmb - 1 - wi);
     if (PAIR) return pass == 0 ? (p.nmb - 1 - wi) : wi;
     return CAUSAL ? (p.nmb - 1 - wi) : wi;
   };
@@ -294,10 +261,6 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     }
   };
   const int tr_pass = (p.dbg & 128) ? 1 : 0;
-  constexpr bool ITR = (VF & VF_IL_ITERTRACE) != 0;
-  static_assert(!ITR || ((VF & VF_IL_EPI) && !(VF & (VF_IL_EPI_INPLACE | VF_IL_KSPLIT))), "ITERTRACE keeps its records in the separate epilogue region");
-  int itr_n = 0, itr_out = 0;                          // records in LDS / already copied out
-  const unsigned long long itr_t0 = ITR ? __builtin_amdgcn_s_memtime() : 0ull;
   if (PREF2) {                                         // the first pass's requests, complete before the loop (see the pass prologue)
     issue_prologue(block_of(0), true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -48,10 +48,9 @@ constexpr int kNumProductVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // ---- A/B arms and measured dead ends: `make EXPERIMENTAL=1` only (tfa_set_variant rejects their numbers otherwise) -------------
 constexpr int kX4Variant = 33;            // il-x4-pair-epi (the x4 kernel at head dims <= 128)
 constexpr int kSeamVariant = 35;          // il8-pair-dmaspread-epi-seam
-// (-DTFA_R4_ARMS alone carries the round-4 arms 38.. without the older kernels: tools/r4_quick.sh builds that into lib_x/ in a minute)
-#if defined(TFA_EXPERIMENTAL) || defined(TFA_R4_ARMS)
-static const Variant kExperimentalVariants[] = {
+// (round 4's arms of the product kernel — numbers 38..62 — are a patch: experiments/r04_il8_arms.patch, docs/LABLOG.md L-9)
 #if defined(TFA_EXPERIMENTAL)
+static const Variant kExperimentalVariants[] = {
     {0, "w8-gatherV (bring-up: 16-bit LDS gathers for V, no transpose read)", 8, 0, 1},
     {1, "w8-trV (8 waves x 32 rows, ds_read_b64_tr_b16 for V)", 8, VF_TRREAD, 1},
     {2, "w4-trV (4 waves x 32 rows, 2 workgroups/CU)", 4, VF_TRREAD, 1},
@@ -84,43 +83,16 @@ static const Variant kExperimentalVariants[] = {
     {31, "il8-pair-dmaspread-epi-pref (+ the next pass's first tiles and Q requested before the epilogue, vmcnt(0) in the prologue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF, 1},
     {33, "il-x4-pair-epi (issue-interleaved, 4 waves x 64 rows: one wave per SIMD, O and Q in AGPRs, K ring of three LDS buffers)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR | VF_X4_EPI, 2},
     {35, "il8-pair-dmaspread-epi-seam (the heavy pass's last tiles stream the light pass's K(0), K(1), V(0); Q before the epilogue)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_SEAM, 1},
-#endif
-    // round 4 (profiles/r04_il8_arms_ab.txt); bf16 D = 128 units only
-    {38, "il8-pair-dmaspread-epi-tail (a wave's last tile runs a pinned softmax-behind-PV body instead of the slow path)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_TAIL, 1},
-    {39, "il8-pair-dmaspread-epi-plain (round 3's default: without the light-pass prefetch of variant 30)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {40, "il8-pair-dmaspread-epi-tail-pref2", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_TAIL | VF_IL_PREF2, 1},
-    {41, "il8-pair-dmaspread-epi-itertrace (debug: per-iteration cycle stamps of every wave, tools/trace_iters.py)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_ITERTRACE, 1},
-    {42, "il8-pair-dmaspread-epi-pf4 (LDS fragments read 4 MFMAs ahead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF4, 1},
-    {43, "il8-pair-dmaspread-epi-pf6 (LDS fragments read 6 MFMAs ahead)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF6, 1},
-    {44, "il8-pair-dmaspread-epi-pf4-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PF4 | VF_IL_ITERTRACE, 1},
-    {45, "il8-pair-dmaspread-epi-idle (the decode instantiation, forced: waves without a valid row skip the tile work)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE, 1},
-    {46, "il8-pair-dmaspread-epi-idle-pf4", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF4, 1},
-    {47, "il8-pair-dmaspread-epi-idle-pf6", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF6, 1},
-    {48, "il8-pair-dmaspread-epi-idle-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_ITERTRACE, 1},
-    {49, "il8-pair-dmaspread-epi-idle-pf4-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_IDLE | VF_IL_PF4 | VF_IL_ITERTRACE, 1},
-    {50, "il8-pair-dmaspread-epi-prioalt8 (the two waves of a SIMD take turns at s_setprio 1 every 8 MFMA slots)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT8, 1},
-    {51, "il8-pair-dmaspread-epi-prioalt4 (turns of 4 MFMA slots)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT4, 1},
-    {52, "il8-pair-dmaspread-epi-dmalow (waves 0-3 issue all LDS-DMA pieces)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_DMALOW, 1},
-    {53, "il8-pair-dmaspread-epi-priohi (static s_setprio 1 for waves 4-7)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOHI, 1},
-    {54, "il8-pair-dmaspread-epi-prioalt8-itertrace", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PRIOALT8 | VF_IL_ITERTRACE, 1},
-    {61, "il8-pair-dmaspread-epi-pref2-lightfirst (variant 30 with the light block of a causal pair first)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF2 | VF_IL_LIGHTFIRST, 1},
-    {62, "il8-pair-dmaspread-epi-lightfirst (round 3's default with the light block first)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_LIGHTFIRST, 1},
-    {55, "il8 ablation: no row max (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {56, "il8 ablation: no LDS fragment reads (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {57, "il8 ablation: no LDS-DMA (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {58, "il8 ablation: no exp/sum/pack, no row max (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {59, "il8 ablation: no softmax, no fragment reads (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
-    {60, "il8 ablation: no barrier (timing only, wrong results)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI, 1},
 };
 constexpr int kNumExperimentalVariants = sizeof(kExperimentalVariants) / sizeof(kExperimentalVariants[0]);
 #endif
-constexpr int kNumVariants = 63;          // variant numbers live in [0, kNumVariants); which of them a build carries: variant_info() != nullptr
+constexpr int kNumVariants = 38;          // variant numbers live in [0, kNumVariants); which of them a build carries: variant_info() != nullptr
 
 // the table entry of a variant number, or nullptr when this build does not carry it
 static inline const Variant* variant_info(int variant) {
   for (int i = 0; i < kNumProductVariants; ++i)
     if (kVariants[i].id == variant) return &kVariants[i];
-#if defined(TFA_EXPERIMENTAL) || defined(TFA_R4_ARMS)
+#if defined(TFA_EXPERIMENTAL)
   for (int i = 0; i < kNumExperimentalVariants; ++i)
     if (kExperimentalVariants[i].id == variant) return &kExperimentalVariants[i];
 #endif
@@ -158,9 +130,6 @@ static inline hipError_t launch_common(Kern kern, std::atomic<unsigned long long
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, a);
   return hipGetLastError();
 }
-
-// timing-only ablations of the il8 kernel (bf16, D = 128, 16-bit out): experiments/csrc/tfa_ilab_inst_bf16_128.hip, variants 55..60 (EXPERIMENTAL builds)
-hipError_t launch_il_ablation(const KArgs& a, int variant, bool causal, hipStream_t s, LaunchGeom* g, bool dry);
 
 // The LDS-DMA kernel 256 wide, fp32 partial output: tfa_fwd_splitkv's one-launch form for head dims above 128 (tfa_dma_inst_<dtype>_256.hip)
 template <typename T>

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 arms library: lib_x/libtfa_hip.so = the product objects of build/ with the bf16 D=128 forward units, tfa_api and the ablation unit rebuilt
+# Round-4 arms library (AFTER `git apply experiments/r04_il8_arms.patch`): lib_x/libtfa_hip.so = the product objects of build/ with the bf16 D=128 forward units, tfa_api and the ablation unit rebuilt
 # with -DTFA_R4_ARMS (the A/B arms 38.. of tfa_launch.h) — about a minute, the product library in lib/ is not touched.
 #   tools/r4_quick.sh            then   TFA_LIB=$PWD/tiny-flash-attention_amd/lib_x/libtfa_hip.so python tools/ab_variants.py --variants 30,61 ...
 set -e
