@@ -598,7 +598,8 @@ int tfa_fwd_work(const tfa_fwd_params* p, double* flops, double* bytes) {
   if (bytes) {
     const double osz = (p->out_dtype == TFA_F32) ? 4.0 : 2.0;
     const double bkv = (double)p->B * p->Hk;
-    *bytes = bh * p->Nq * p->D * 2.0 + 2.0 * bkv * p->Nk * p->D * 2.0 + bh * p->Nq * p->D * osz +
+    const double isz = (p->dtype == TFA_F32) ? 4.0 : 2.0;
+    *bytes = bh * p->Nq * p->D * isz + 2.0 * bkv * p->Nk * p->D * isz + bh * p->Nq * p->D * osz +
              (p->lse ? bh * p->Nq * 4.0 : 0.0);
   }
   return TFA_OK;
