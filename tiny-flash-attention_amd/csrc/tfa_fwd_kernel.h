@@ -37,6 +37,21 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
+// Division of a non-negative int below 2^31 by a launch constant: (umulhi(n, m) + n) >> l — three scalar instructions where hipcc's signed
+// division is about thirty (round 4: a workgroup's start-up is bound by instruction issue, docs/LABLOG.md L-10)
+struct FastDiv {
+  unsigned m, l;
+};
+static inline FastDiv fastdiv_of(unsigned d) {     // d >= 1
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  FastDiv f;
+  f.m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  f.l = l;
+  return f;
+}
+static __device__ __forceinline__ int fd_div(int n, FastDiv f) { return (int)((__umulhi((unsigned)n, f.m) + (unsigned)n) >> f.l); }
+
 // Kernel arguments (device view of tfa_fwd_params; strides in ELEMENTS).
 struct KArgs {
   const void* q;
@@ -71,6 +86,14 @@ struct KArgs {
                     // read as zeros (their LDS-DMA lanes / Q loads are pointed outside the buffer) and never stored
   int dbg;          // bring-up flags (tfa_debug_set_flags; 0 in normal use).  128: the trace stamps describe the workgroup's
                     // SECOND pass (t[0] = its start) instead of the first; low bits: tfa_fwd_kernel_x4.h
+  // work-item decode of fwd_kernel_il, filled by launch_common (tfa_launch.h: fill_decode) from the fields above
+  // One branch-free form for the three orders (so that hipcc fetches every kernel argument the decode needs in one burst):
+  //   x = rr ? id & 7 : 0, s = rr ? id >> 3 : id;  sq = s / wa, r = s % wa;  kg = rr ? x + 8 sq : sq;  rq = r / nwork, wi = r % nwork;
+  //   b = kg / wd, m = kg % wd;  h = m * wg + rq;  hk = h / G
+  //   GQA with (B * Hk) % 8 == 0: K/V heads round-robin over the XCDs, the G query heads of one stay on its XCD: rr = 1, wa = G * nwork, wd = Hk, wg = G
+  //   B * H % 8 == 0: heads round-robin over the XCDs: rr = 1, wa = nwork, wd = H, wg = 1  (rq = 0);   else plain (b,h)-major: rr = 0, same
+  int rr, wa, wd, wg, G;
+  FastDiv fd_wa, fd_wd, fd_nwork, fd_g;
   int kv_stream;    // K and V together reach 768 MiB — a cache the 256 MB memory-side cache cannot keep until the next call: decode
                     // kernels whose K/V tiles no other workgroup reads may stream them with the non-temporal hint (set by the host)
 };

@@ -32,6 +32,7 @@
 
 namespace tfa {
 
+
 constexpr int VF_IL = 32768;        // issue-interleaved kernel (this file)
 constexpr int VF_IL_DMASPREAD = 65536;   // issue the LDS-DMA pieces between MFMAs of part 1 instead of at the top
 constexpr int VF_IL_EPI = 262144;        // 16-bit O leaves through a separate LDS region as whole rows (16-byte coalesced stores)
@@ -56,6 +57,9 @@ constexpr int VF_IL_PREF2 = 1 << 29;     // paired causal blocks: the light pass
                                          // its O stores, and waited for with a COUNTED vmcnt behind them — vmcnt retires in issue order, so the light prologue
                                          // never waits for the stores' write acknowledges (round 4: light prologue 6.9 k -> 3.1 k cycles, +0.8 % on the headline;
                                          // earlier requests — inside the loop — cost the loop more registers than they save: docs/LABLOG.md L-9)
+constexpr int VF_IL_QLDS = 1 << 28;      // the FIRST prologue of a workgroup brings Q in through LDS: a wave's 32 rows by LDS-DMA into its slice of the (idle)
+                                         // epilogue region — whole 1 KiB pieces, 64 cache lines per wave instead of 256 32-byte segments — and the eight
+                                         // fragments back with ds_read_b128 (the K tile's swizzle).  Later passes load Q as before (registers, PREF2)
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
                                          // so the two waves of a SIMD never sit in an LDS-DMA issue stall at the same time
 
@@ -65,6 +69,11 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
 namespace tfa {
 
 // AB: timing-only ablation bits of the fast path (results are wrong when set; tools/ablate_il.py)
+// (ILAB_TRACE is not an ablation: the instantiation that writes the per-workgroup cycle stamps of tfa_debug_set_trace.  The stamps' scalar
+//  state — four 64-bit counters live from the first instruction to the last — cost every workgroup ~130 v_readlane / v_writelane, so the
+//  kernels the library dispatches are compiled without it and a traced twin is launched when a trace buffer is set: tfa_fwd_inst.inc)
+constexpr int ILAB_TRACE = 256;
+#define P_TRACE ((AB & ILAB_TRACE) ? p.trace : (unsigned long long*)nullptr)
 constexpr int ILAB_NOEXP = 1, ILAB_NODMA = 2, ILAB_NOBARRIER = 4, ILAB_NOMAX = 8, ILAB_NOQK = 16, ILAB_NOPV = 32, ILAB_NOKREAD = 64, ILAB_NOVREAD = 128;
 
 // DVB: 32-wide column blocks that can hold valid head-dim columns (default: all of them).  D / 32 - 1 is instantiated for the two main
@@ -109,6 +118,10 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   static_assert(PPW >= 1 && PPW * NWG == PIECES, "tile does not split into whole DMA pieces per wave");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
+  // A workgroup's start-up is bound by instruction issue, and the older wave of a SIMD wins every issue slot it can use: the younger wave's first
+  // memory requests used to go out ~4 k cycles after the older one's (tools/trace_prologue.py).  Until its requests are out a wave runs at
+  // priority 1, afterwards at 0: the wave that still has to ask for its data goes first.
+  asm volatile("s_setprio 1" ::: "memory");
   const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = KSPLIT ? wave_id / NWG : 0;      // key-tile group of this wave (KSPLIT), its own four tile buffers
   char* const gsm = smem + grp * 4 * TILE_BYTES;
@@ -117,9 +130,26 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)gsm;
 
   unsigned long long t_start = 0, t_pro = 0, t_loop = 0, rt_start = 0;
-  if (p.trace) { rt_start = __builtin_amdgcn_s_memrealtime(); t_start = __builtin_amdgcn_s_memtime(); }
+#if defined(TFA_IL_TRACEPRO)
+  const unsigned long long tp_entry = __builtin_amdgcn_s_memtime();      // before the first kernel argument has arrived
+#endif
+  if (P_TRACE) { rt_start = __builtin_amdgcn_s_memrealtime(); t_start = __builtin_amdgcn_s_memtime(); }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+#if defined(TFA_IL_TRACEPRO)
+  // start-up stamps k = 0..7 of every wave, stored at once (they sit in front of the first LDS-DMA: no counted vmcnt wait sees the stores)
+#define TP_STAMP(k, dep)                                                                                                         \
+  do {                                                                                                                             \
+    asm volatile("" ::"s"(dep));                                                                                                   \
+    if (P_TRACE) {                                                                                                                 \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                                  \
+      P_TRACE[(size_t)gridDim.x * 8 + (size_t)gridDim.x * 32 + ((size_t)blockIdx.x * 8 + wave_id) * 8 + (k)] = t_; /* (every lane, same value) */ \
+    }                                                                                                                              \
+  } while (0)
+  if (P_TRACE) P_TRACE[(size_t)gridDim.x * 8 + (size_t)gridDim.x * 32 + ((size_t)blockIdx.x * 8 + wave_id) * 8 + 0] = tp_entry;
+#else
+#define TP_STAMP(k, dep)
+#endif
   const int wave = KSPLIT ? wave_id % NWG : wave_id;   // index inside the query block: rows, DMA pieces, epilogue slice
   // the 32-row block of a wave (a permutation that evens out the diagonal block's tiles per SIMD — {0,1,2,3,7,6,5,4} — measured
   // neutral: the per-tile barrier sets the diagonal's wall time whatever the map; profiles/r02_window_ab2.txt)
@@ -127,29 +157,24 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   const int qi = lane & 31;
   const int hi = lane >> 5;
 
-  int bh, wi;
+  // work item -> (b, h, hk, wi).  Divisions by launch constants through the host's magic numbers (FastDiv), one branch-free form for the three
+  // orders (KArgs::rr ..): this decode is on the critical path of every workgroup's first memory request, and the two waves of a SIMD run it
+  // one behind the other.  GQA: the G query heads of a K/V head stay on ONE XCD (its K/V tiles are fetched into one L2 instead of G)
+  int bh, wi, b, h, hk;
   {
     const int id = blockIdx.x;
-    const int G = p.H / p.Hk;
-    if (G > 1 && ((p.B * p.Hk) & 7) == 0) {
-      // GQA: the G query heads of a K/V head stay on ONE XCD (its K/V tiles are fetched into one L2 instead of G), K/V heads
-      // round-robin over the XCDs: XCD x works through K/V heads x, x+8, ... and, inside one, through its query heads
-      const int x = id & 7, s = id >> 3;
-      const int per = G * p.nwork, kg = x + 8 * (s / per), r = s % per;
-      bh = (kg / p.Hk) * p.H + (kg % p.Hk) * G + r / p.nwork;
-      wi = r % p.nwork;
-    } else if ((p.nbh & 7) == 0) {
-      const int x = id & 7, s = id >> 3;
-      bh = x + 8 * (s / p.nwork);
-      wi = s % p.nwork;
-    } else {
-      bh = id / p.nwork;
-      wi = id % p.nwork;
-    }
+    const int x = p.rr ? (id & 7) : 0, s = p.rr ? (id >> 3) : id;
+    const int sq = fd_div(s, p.fd_wa), r = s - sq * p.wa;
+    const int kg = p.rr ? x + 8 * sq : sq;
+    const int rq = fd_div(r, p.fd_nwork);
+    wi = r - rq * p.nwork;
+    b = fd_div(kg, p.fd_wd);
+    h = (kg - b * p.wd) * p.wg + rq;
+    hk = fd_div(h, p.fd_g);
+    bh = b * p.H + h;
   }
-  const int b = bh / p.H;
-  const int h = bh - b * p.H;
-  const int hk = h / (p.H / p.Hk);
+  __builtin_assume(b >= 0 && h >= 0 && hk >= 0);     // (64-bit stride products without the sign terms)
+  TP_STAMP(1, bh + wi + hk);                           // work item decoded
   const int shift = p.shift;
 
   const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
@@ -166,6 +191,11 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     k_bytes = k_bytes > ko ? k_bytes - ko : 0;
     v_bytes = v_bytes > vo ? v_bytes - vo : 0;
   }
+  // descriptor of a Q / O slice: the whole slice (the host guarantees < 2 GiB for the instantiations that are not WINDOWED), or from `off` on
+  auto slice_rsrc = [&](const void* base, unsigned long long bytes, unsigned long long off) {
+    if constexpr (WIN) return rsrc_at(base, bytes, off);
+    else return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)bytes, 0x00020000);
+  };
   auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, WIN ? 0u : (unsigned)k_bytes, 0x00020000);
   auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, WIN ? 0u : (unsigned)v_bytes, 0x00020000);
 
@@ -192,6 +222,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 
   // (query heads that share a K/V head share its tiles in L2: no streaming hint then; nor for a K/V cache that the 256 MB memory-side
   //  cache can keep until the next decode step — the host sets KArgs::kv_stream from 768 MiB on: profiles/r03_decode_nt_ab.txt)
+  TP_STAMP(2, (int)(size_t)qbase + (int)(size_t)kbase + (int)(size_t)vbase);   // base pointers
   const bool kv_private = p.H == p.Hk && p.kv_stream != 0;
   auto dma_k1 = [&](int t, int buf, int i) {
     if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(kbase, k_bytes, (unsigned long long)t * (unsigned)k_tile_stride), lds_base + buf * TILE_BYTES + (wave * PPW + i) * 1024, k_src[i]);
@@ -222,9 +253,15 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   int nt_total = 0, n_slow = 0;
   unsigned long long tw_wait = 0, tw_bar = 0;   // TFA_IL_TRACEWAIT debug sums
 
+#if defined(TFA_IL_TRACEPRO)
+  asm volatile("" ::"v"(k_src[0]), "v"(v_src[PPW - 1]));
+#endif
+  TP_STAMP(3, wi);                                     // lane offsets of the DMA pieces (in front of the first request)
   const int npass = PAIR ? ((p.nmb - 1 - wi) != wi ? 2 : 1) : 1;
   constexpr bool EPI = (VF & VF_IL_EPI) != 0;
   constexpr bool PREF2 = PAIR && (VF & VF_IL_PREF2) != 0;
+  constexpr bool QLDS = (VF & VF_IL_QLDS) != 0;
+  static_assert(!QLDS || ((VF & VF_IL_EPI) && !(VF & (VF_IL_EPI_INPLACE | VF_IL_KSPLIT | VF_IL_WINDOWED | VF_IL_IDLE | VF_IL_SEAM))), "QLDS: a wave-private slice of the separate epilogue region");
   // store instructions of O per pass and wave (the epilogue's three forms: fp32 direct, 16-bit rows through LDS, 16-bit direct)
   constexpr int NST_EPI = F32OUT ? 4 * DT : ((VF & VF_IL_EPI) ? 32 / (64 / (D / 8)) : 4 * DT);
   constexpr bool PREF = (VF & VF_IL_PREF) != 0 || PREF2;
@@ -252,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     if (with_dma && ntx > 0) dma_k(0, 0);
     if (with_dma && ntx > 0) dma_v(0, 0);
     if (with_dma && ntx > 1) dma_k(1, 1);
-    auto q_rs = rsrc_at(qbase, p.q_bytes, WIN ? (unsigned long long)q0x * (unsigned long long)p.qs_n * 2ull : 0ull);
+    auto q_rs = slice_rsrc(qbase, p.q_bytes, (unsigned long long)q0x * (unsigned long long)p.qs_n * 2ull);
     const int qoff = ((WIN ? 0 : q0x) + wrow * 32 + qi) * (int)p.qs_n * 2 + hi * 16;
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
@@ -260,17 +297,83 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       qf[s] = __builtin_bit_cast(X8, t);
     }
   };
+  // ---- QLDS: this wave's 32 rows of query block mbx into its slice of the epilogue region; the fragments out of it
+  const unsigned q_slice = lds_base + 4 * TILE_BYTES + wave * (32 * D * 2);
+  auto issue_q_dma = [&](int mbx) {
+    constexpr int RPP = 1024 / (D * 2);                // rows per 1 KiB piece
+    auto q_rs = slice_rsrc(qbase, p.q_bytes, 0ull);
+    const int r0 = __builtin_amdgcn_readfirstlane(mbx * BM + wave * 32);   // (uniform on purpose: hipcc otherwise carries it in a VGPR into the pass loop)
+#pragma unroll
+    for (int i = 0; i < 32 / RPP; ++i) {
+      const int row = i * RPP + lane / CPR, cpos = lane % CPR;
+      const int kch = cpos ^ k_swz<D>(row);            // the K tile's image: position cpos of a row holds its chunk cpos ^ swz(row)
+      const int off = kch * 8 < p.dv ? (r0 + row) * (int)p.qs_n * 2 + (kch << 4) : (int)TFA_OOB;
+      lds_dma16_m0(q_rs, __builtin_amdgcn_readfirstlane(q_slice) + i * 1024, off);
+    }
+  };
+  auto read_q_lds = [&]() {
+    typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+      const unsigned a = q_slice + qi * (D * 2) + ((((2 * s + hi) ^ k_swz<D>(qi))) << 4);
+      qf[s] = __builtin_bit_cast(X8, *reinterpret_cast<lds_u32x4*>(a));
+    }
+  };
+  // a workgroup's first requests: K(0), the Q rows, then V(0) and K(1) — the first barrier needs only K(0) and Q, so the wait in front of it
+  // (wait_first) leaves the two younger tiles in flight behind S(0) = K(0) Q^T; the barrier in front of the tile loop waits for them
+  int first_late = 0;                                  // 0: nothing issued behind Q, 1: V(0), 2: V(0) and K(1)
+  auto issue_first = [&](int mbx) {
+    const int q0x = mbx * BM;
+    int kve = p.Nk;
+    if (CAUSAL) { const int lim = q0x + BM + shift; kve = lim < kve ? lim : kve; }
+    const int ntx = kve > 0 ? (kve + BN - 1) / BN : 0;
+    if (ntx > 0) dma_k(0, 0);
+    issue_q_dma(mbx);
+    if (ntx > 0) dma_v(0, 0);
+    if (ntx > 1) dma_k(1, 1);
+    first_late = ntx > 1 ? 2 : (ntx > 0 ? 1 : 0);
+  };
+  auto wait_first = [&]() {                            // vmcnt retires in issue order: K(0) and Q are the oldest requests
+    if (first_late == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    else if (first_late == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   const int tr_pass = (p.dbg & 128) ? 1 : 0;
+#if defined(TFA_IL_TRACEPRO)
+  unsigned long long tp_issue = 0, tp_kv = 0, tp_q = 0, tp_bar = 0;
+  const unsigned long long tp_t0 = t_start;
+#endif
   if (PREF2) {                                         // the first pass's requests, complete before the loop (see the pass prologue)
-    issue_prologue(block_of(0), true);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (QLDS) issue_first(block_of(0));
+    else issue_prologue(block_of(0), true);
+    __builtin_amdgcn_sched_barrier(0);                 // (the loop's hoisted invariants stay behind the requests)
+    asm volatile("s_setprio 0" ::: "memory");
+    o_zero<DT>();                                      // (work that needs no data goes in front of the wait)
+#if defined(TFA_IL_TRACEPRO)
+    // debug build (tools/trace_prologue.py): when were the first requests out, when had K(0)/V(0)/K(1) landed (the 3 * PPW DMA pieces are the
+    // OLDEST requests: vmcnt retires in order), when the Q fragments
+    if (P_TRACE) {
+      tp_issue = __builtin_amdgcn_s_memtime();
+      if (QLDS) {                                      // K(0) and Q are the oldest requests here: one stamp for both
+        wait_first();
+        tp_kv = tp_q = __builtin_amdgcn_s_memtime();
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DS) : "memory");
+        tp_kv = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tp_q = __builtin_amdgcn_s_memtime();
+      }
+    }
+#endif
+    if (QLDS) { wait_first(); read_q_lds(); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));
   }
 #pragma nounroll
   for (int pass = 0; pass < npass; ++pass) {
     const int mb = block_of(pass);
-    if (p.trace && pass == 1 && tr_pass == 1) t_start = __builtin_amdgcn_s_memtime();
+    if (P_TRACE && pass == 1 && tr_pass == 1) t_start = __builtin_amdgcn_s_memtime();
     const int q0 = mb * BM;
     // query POSITIONS of the wave's rows (for the causal mask): rows themselves, or — packed GQA heads, decode instantiation
     // only — row % row_mod, in which case a wave's rows span every position 0 .. row_mod-1
@@ -400,24 +503,36 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #include "tfa_fwd_il_epilogue.inc"
   }
 
-  if (p.trace) {
+  if (P_TRACE) {
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     if (tid == 0) {
-      unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
+      unsigned long long* t = P_TRACE + (size_t)blockIdx.x * 8;
       t[0] = t_start; t[1] = t_pro; t[2] = t_loop; t[3] = t_end;
 #if defined(TFA_IL_TRACEWAIT)
       t[1] = t_start + tw_wait; t[2] = t_start + tw_wait + tw_bar;   // debug: "prologue" = memory waits, "loop" = barrier waits of wave 0
 #endif
       t[4] = (unsigned long long)nt_total | ((unsigned long long)n_slow << 32);   // wave 0's slow-path tiles in the high half
       t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63508) | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32);   // XCC_ID | HW_ID << 32
+#if defined(TFA_IL_TRACEPRO)
+      t[4] = ((tp_issue - t_start) & 0xffffffffull) | ((tp_kv - t_start) << 32);
+      t[5] = (t[5] & 0xffffffffull) | ((tp_q - t_start) << 32);
+#endif
       t[6] = __builtin_amdgcn_s_memrealtime() - rt_start;   // 100 MHz ticks over the same span as t[3] - t[0] shader cycles
       t[7] = ((unsigned long long)bh << 32) | (unsigned)wi;
     }
+#if defined(TFA_IL_TRACEPRO)
+    if (lane == 0) {                                   // per wave: start, requests out, Q landed, at the first barrier
+      unsigned long long* tw = P_TRACE + (size_t)gridDim.x * 8 + ((size_t)blockIdx.x * 8 + wave_id) * 4;
+      tw[0] = tp_t0; tw[1] = tp_issue; tw[2] = tp_q; tw[3] = tp_bar;
+    }
+#endif
   }
 }
 
 #undef KT
+#undef P_TRACE
+#undef TP_STAMP
 #undef KS
 
 }  // namespace tfa

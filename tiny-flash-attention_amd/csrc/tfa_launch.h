@@ -35,7 +35,8 @@ constexpr int kSplitVariant = 17;         // dma4-2buf: the kernel whose grid ca
 static const Variant kVariants[] = {
     {17, "dma4-pair-2buf (LDS-DMA, burst-structured, exact running max; 128-row blocks, two LDS buffers: two workgroups per CU)", 4, VF_DMA | VF_PAIR | VF_2BUF, 1},
     {30, "il8-pair-dmaspread-epi (issue-interleaved, 8 waves; O leaves through a separate LDS region as whole rows, 16-byte stores; causal pairs: the light "
-         "pass is requested before the heavy pass's O stores)", 8, VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF2, 1},
+         "pass is requested before the heavy pass's O stores; a workgroup's first Q rows arrive through LDS)", 8,
+     VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF2 | VF_IL_QLDS, 1},
     {32, "il4-pair-epi (4 waves x2 workgroups per CU; O leaves through the idle tile buffers as whole rows)", 4, VF_DMA | VF_IL | VF_PAIR | VF_IL_EPI | VF_IL_EPI_INPLACE, 1},
     {34, "x4-d256-pair (the x4 kernel with ONE 32-row block per wave: head dims 136..256, 128-row workgroups, O stored directly)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR, 1},
     {36, "il8-ksplit-epi (small grids: 8 waves on one 128-row block, waves 0-3 take the even KV tiles and waves 4-7 the odd ones, merged through LDS)", 8,
@@ -119,11 +120,29 @@ static inline hipError_t launch_fwd(const KArgs& a, bool causal, bool f32out, in
 
 // common tail of every launcher: report the geometry, opt in to the dynamic LDS size on this device, launch, and return
 // THIS launch's status (a sticky error left behind by unrelated earlier HIP calls is cleared first).
+// the launch constants of the kernels' work-item decode (KArgs::wmode ..): every launch goes through launch_common, so no caller can forget them
+static inline void fill_decode(KArgs* a) {
+  a->G = a->Hk > 0 ? a->H / a->Hk : 1;
+  if (a->G < 1) a->G = 1;
+  const int nwork = a->nwork > 0 ? a->nwork : 1;
+  const bool gqa_rr = a->G > 1 && ((a->B * a->Hk) & 7) == 0;
+  a->rr = (gqa_rr || (a->nbh & 7) == 0) ? 1 : 0;
+  a->wa = gqa_rr ? a->G * nwork : nwork;
+  a->wd = gqa_rr ? a->Hk : (a->H > 0 ? a->H : 1);
+  a->wg = gqa_rr ? a->G : 1;
+  a->fd_wa = fastdiv_of(a->wa);
+  a->fd_wd = fastdiv_of(a->wd);
+  a->fd_nwork = fastdiv_of(nwork);
+  a->fd_g = fastdiv_of(a->G);
+}
+
 template <typename Kern>
 static inline hipError_t launch_common(Kern kern, std::atomic<unsigned long long>& mask, int grid, int block, int lds,
-                                       const KArgs& a, hipStream_t stream, LaunchGeom* geom, bool dry) {
+                                       const KArgs& a_in, hipStream_t stream, LaunchGeom* geom, bool dry) {
   if (geom) { geom->grid = grid; geom->block = block; geom->lds = lds; }
   if (dry) return hipSuccess;
+  KArgs a = a_in;
+  fill_decode(&a);
   hipError_t e = set_dyn_lds_once(mask, reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   (void)hipGetLastError();
