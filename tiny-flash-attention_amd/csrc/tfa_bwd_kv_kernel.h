@@ -58,6 +58,9 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   constexpr int ST_OFF = NSTAGE * STAGE_BYTES + 2 * KG * PX_BYTES;   // per stage: LSE of the tile's 64 query rows (256 B), delta (256 B)
   const char* const sbuf = smem + ST_OFF;
 
+#if defined(TFA_BWD_TRACE)
+  const unsigned long long tw_entry = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -359,10 +362,7 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   }
 
 #if defined(TFA_BWD_TRACE)
-  if (p.tr != nullptr && lane == 0) {
-    unsigned long long* tr = reinterpret_cast<unsigned long long*>(p.tr) + ((size_t)blockIdx.x * NW + wave) * 4;
-    tr[0] = __builtin_amdgcn_s_memtime() - tw_t0; tr[1] = tw_mem; tr[2] = tw_bar; tr[3] = (unsigned long long)nu;
-  }
+  const unsigned long long tw_t1 = __builtin_amdgcn_s_memtime();
 #endif
   // ---- epilogue: role 0 writes dV, role 1 writes dK * scale.  acc[dt][r] = grad[row my_row][32*dt + (r&3) + 8*(r>>2) + 4*hi] ----
   const float osc = role ? p.scale : 1.f;
@@ -383,18 +383,45 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), g_rs, d * 32 + g4 * 8 + hi * 4 < p.dv ? goff + (d * 32 + g4 * 8) * 4 : (int)TFA_OOB, 0, 0);
       }
   } else {
+    // A lane holds 4-element pieces of ONE gradient row spread over 16 register groups: stored directly that is 16 eight-byte stores per lane,
+    // 32 different rows per instruction — 7.5 k cycles behind the tile loop (tools/trace_bwd_kv.py), a twentieth of a workgroup's life.  As in the
+    // forward's epilogue (tfa_fwd_il_epilogue.inc) the wave transposes its 32 x D tile through its own slice of the (now idle) tile stages —
+    // 16-byte chunk index XOR row — and writes whole rows: 1 KiB contiguous per store instruction.  Every wave is behind the loop's last barrier.
     T* gb = reinterpret_cast<T*>(gp) + b * gsb + hr * gsh;
     auto g_rs = BIG ? rsrc_at(gb, gfull, (unsigned long long)r0 * (unsigned long long)gsn * 2ull) : __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, gbytes, 0x00020000);
-    const int goff = (my_row - (BIG ? r0 : 0)) * gsn * 2 + hi * 8;
     typedef __attribute__((ext_vector_type(4))) T t4;
+    static_assert(NW * 32 * D * 2 <= NSTAGE * STAGE_BYTES, "one 32 x D slice per wave inside the tile stages");
+    // (the lane ids go through an empty asm: nothing below is computed in front of the tile loop and kept live across it)
+    int qix = qi, lanex = lane, hix = hi;
+    asm volatile("" : "+v"(qix), "+v"(lanex), "+v"(hix));
+    char* const ow = smem + wave * (32 * D * 2);
+    constexpr int CH = D / 8;                        // 16-byte chunks per row
+    const int osw = (CH == 16) ? (qix & 15) : (qix & 7);
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         t4 v4 = {(T)(acc[d][4 * g4 + 0] * osc), (T)(acc[d][4 * g4 + 1] * osc), (T)(acc[d][4 * g4 + 2] * osc), (T)(acc[d][4 * g4 + 3] * osc)};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), g_rs, d * 32 + g4 * 8 + hi * 4 < p.dv ? goff + (d * 32 + g4 * 8) * 2 : (int)TFA_OOB, 0, 0);
+        const int c = d * 4 + g4;
+        *reinterpret_cast<u32x2*>(ow + qix * (D * 2) + ((c ^ osw) << 4) + hix * 8) = __builtin_bit_cast(u32x2, v4);
       }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slice: no barrier needed
+    constexpr int RPI = 64 / CH;                     // rows per store instruction (4 at D = 128, 8 at D = 64)
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int r = i * RPI + lanex / CH, cpos = lanex % CH;
+      const int c = cpos ^ ((CH == 16) ? (r & 15) : (r & 7));
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
+      __builtin_amdgcn_raw_buffer_store_b128(v, g_rs, c * 8 < p.dv ? (wave_row0 - (BIG ? r0 : 0) + r) * gsn * 2 + (c << 4) : (int)TFA_OOB, 0, 0);
+    }
   }
+#if defined(TFA_BWD_TRACE)
+  if (p.tr != nullptr && lane == 0) {                  // tiles | cycles from kernel entry to the tile loop << 16 | cycles behind the loop << 40
+    unsigned long long* tr = reinterpret_cast<unsigned long long*>(p.tr) + ((size_t)blockIdx.x * NW + wave) * 4;
+    const unsigned long long pro = (tw_t0 - tw_entry) & 0xffffffull, epi = (__builtin_amdgcn_s_memtime() - tw_t1) & 0xffffffull;
+    tr[0] = tw_t1 - tw_t0; tr[1] = tw_mem; tr[2] = tw_bar; tr[3] = (unsigned long long)nu | (pro << 16) | (epi << 40);
+  }
+#endif
 }
 
 }  // namespace tfa

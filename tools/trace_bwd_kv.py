@@ -33,7 +33,18 @@ _lib.debug_bwd_split(0)
 t = ws[need:].view(torch.int64).cpu().view(-1, 4)
 nwg = (N // 128) * B * H if True else 0
 t = t[: nwg * 8].view(nwg, 8, 4).double()
-tot, mem, bar, nu = t[..., 0], t[..., 1], t[..., 2], t[..., 3]
+tot, mem, bar = t[..., 0], t[..., 1], t[..., 2]
+t3 = t[..., 3].long()
+nu, pro, epi = (t3 & 0xffff).double(), ((t3 >> 16) & 0xffffff).double(), ((t3 >> 40) & 0xffffff).double()
+# workgroup anatomy: kernel entry -> tile loop (max over waves), the loop, behind the loop (stores issued; max over waves)
+wg_pro, wg_loop, wg_epi, wg_nu = pro.max(dim=1).values, tot.max(dim=1).values, epi.max(dim=1).values, nu[:, 0]
+print(f"workgroup anatomy (cycles): entry->loop median {wg_pro.median():.0f} (p10 {wg_pro.quantile(0.1):.0f} p90 {wg_pro.quantile(0.9):.0f}); behind the loop median {wg_epi.median():.0f}; "
+      f"loop per tile median {(wg_loop / wg_nu.clamp(min=1)).median():.0f}; sum over workgroups: entry->loop {100 * wg_pro.sum() / (wg_pro + wg_loop + wg_epi).sum():.1f} %, "
+      f"loop {100 * wg_loop.sum() / (wg_pro + wg_loop + wg_epi).sum():.1f} %, behind {100 * wg_epi.sum() / (wg_pro + wg_loop + wg_epi).sum():.1f} %")
+for lo, hi_ in ((1, 8), (8, 24), (24, 48), (48, 65)):
+    m = (wg_nu >= lo) & (wg_nu < hi_)
+    if m.any():
+        print(f"   workgroups with {lo}..{hi_ - 1} tiles: {int(m.sum())}; entry->loop {wg_pro[m].median():.0f}, loop per tile {(wg_loop[m] / wg_nu[m]).median():.0f}, behind the loop {wg_epi[m].median():.0f}")
 print(f"{a.cfg}{' (workspace form)' if a.ws else ''}: {nwg} workgroups x 8 waves; wave life mean {tot.mean():.0f} cycles (100 MHz ticks x?), tiles per workgroup {nu.min():.0f}..{nu.max():.0f}")
 for role, sl in (("role 0 (waves 0-3: S, P, dV)", slice(0, 4)), ("role 1 (waves 4-7: dP, dS, dK)", slice(4, 8))):
     T, M, Bq = tot[:, sl].sum(), mem[:, sl].sum(), bar[:, sl].sum()
