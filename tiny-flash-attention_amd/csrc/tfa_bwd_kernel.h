@@ -474,17 +474,36 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), g_rs, d * 32 + g4 * 8 + hi * 4 < p.dv ? goff + (d * 32 + g4 * 8) * 4 : (int)TFA_OOB, 0, 0);
       }
   } else {
+    // Whole rows through LDS instead of 16 eight-byte stores per lane over 32 different rows (tfa_bwd_kv_kernel.h's epilogue, the forward's
+    // tfa_fwd_il_epilogue.inc): the wave transposes its 32 x D tile through its own slice of the idle tile stages (16-byte chunk index XOR
+    // row) and stores 16 bytes per lane, 1 KiB contiguous per instruction.  Every wave is behind the tile loop's last barrier.
     T* gb = reinterpret_cast<T*>(p.grad) + b * p.gs_b + hr * p.gs_h;
     auto g_rs = BIG ? rsrc_at(gb, p.g_full, (unsigned long long)r0 * (unsigned long long)p.gs_n * 2ull) : __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, p.g_bytes, 0x00020000);
-    const int goff = (my_row - (BIG ? r0 : 0)) * (int)p.gs_n * 2 + hi * 8;
     typedef __attribute__((ext_vector_type(4))) T t4;
+    static_assert(NW * 32 * D * 2 <= 2 * NIMG * TILE_BYTES, "one 32 x D slice per wave inside the tile stages");
+    // (the lane ids go through an empty asm: nothing below is computed in front of the tile loop and kept live across it)
+    int qix = qi, lanex = lane, hix = hi;
+    asm volatile("" : "+v"(qix), "+v"(lanex), "+v"(hix));
+    char* const ow = smem + wave * (32 * D * 2);
+    constexpr int CH = D / 8;                        // 16-byte chunks per row
+    const int osw = (CH >= 16) ? (qix & 15) : (qix & 7);
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         t4 v4 = {(T)(ga(d, 4 * g4 + 0) * osc), (T)(ga(d, 4 * g4 + 1) * osc), (T)(ga(d, 4 * g4 + 2) * osc), (T)(ga(d, 4 * g4 + 3) * osc)};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v4), g_rs, d * 32 + g4 * 8 + hi * 4 < p.dv ? goff + (d * 32 + g4 * 8) * 2 : (int)TFA_OOB, 0, 0);
+        const int c = d * 4 + g4;
+        *reinterpret_cast<u32x2*>(ow + qix * (D * 2) + ((c ^ osw) << 4) + hix * 8) = __builtin_bit_cast(u32x2, v4);
       }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slice: no barrier needed
+    constexpr int RPI = 64 / CH;                     // rows per store instruction (2 at D = 256, 4 at D = 128, 8 at D = 64)
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int r = i * RPI + lanex / CH, cpos = lanex % CH;
+      const int c = cpos ^ ((CH >= 16) ? (r & 15) : (r & 7));
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
+      __builtin_amdgcn_raw_buffer_store_b128(v, g_rs, c * 8 < p.dv ? (wave_row0 - (BIG ? r0 : 0) + r) * (int)p.gs_n * 2 + (c << 4) : (int)TFA_OOB, 0, 0);
+    }
   }
 }
 

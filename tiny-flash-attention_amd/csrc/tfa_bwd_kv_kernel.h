@@ -165,9 +165,25 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
     const BTensor& x = role ? p.v : p.k;
     const T* b1 = reinterpret_cast<const T*>(x.p) + b * x.s_b + hr * x.s_h;
     auto rs1 = BIG ? rsrc_at(b1, x.full, (unsigned long long)r0 * (unsigned long long)x.s_n * 2ull) : __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, x.bytes, 0x00020000);
-    const int off1 = (my_row - (BIG ? r0 : 0)) * (int)x.s_n * 2 + hi * 16;
+    if constexpr (KG == 4) {
+      // Through LDS (the forward's first prologue, VF_IL_QLDS): the wave's 32 rows arrive by LDS-DMA as whole 1 KiB pieces — 64 cache lines per wave
+      // instead of 256 32-byte segments — in its slice of stages 1 and 2 (idle until iteration 0 requests tile 1, behind the barrier below),
+      // chunk position XOR u_swz(row); the fragments are read back once tile 0 has been requested
+      constexpr int RPP = 1024 / (D * 2);            // rows per piece
+      const unsigned slice = __builtin_amdgcn_readfirstlane(lds_base + STAGE_BYTES + wave * (32 * D * 2));
+      int lanex = lane;                              // (through an empty asm: this one-off address math shares nothing with the tile loop's)
+      asm volatile("" : "+v"(lanex));
 #pragma unroll
-    for (int s = 0; s < DS; ++s) rf[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs1, (2 * s + hi) * 8 < p.dv ? off1 + s * 32 : (int)TFA_OOB, 0, 0));
+      for (int i = 0; i < 32 / RPP; ++i) {
+        const int row = i * RPP + lanex / CPR, cpos = lanex % CPR;
+        const int ch = cpos ^ u_swz<D>(row);
+        lds_dma16_m0(rs1, slice + i * 1024, ch * 8 < p.dv ? (wave_row0 - (BIG ? r0 : 0) + row) * (int)x.s_n * 2 + (ch << 4) : (int)TFA_OOB);
+      }
+    } else {
+      const int off1 = (my_row - (BIG ? r0 : 0)) * (int)x.s_n * 2 + hi * 16;
+#pragma unroll
+      for (int s = 0; s < DS; ++s) rf[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs1, (2 * s + hi) * 8 < p.dv ? off1 + s * 32 : (int)TFA_OOB, 0, 0));
+    }
   }
 
   f32x16 acc[DT];
@@ -214,9 +230,16 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
 
   if (nu > 0) dma_next(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (KG == 4) {
+    const char* const sl = smem + STAGE_BYTES + wave * (32 * D * 2);
+    int qix = qi, hix = hi;
+    asm volatile("" : "+v"(qix), "+v"(hix));
+#pragma unroll
+    for (int s = 0; s < DS; ++s) rf[s] = __builtin_bit_cast(X8, lds_read_b128(sl, qix * (D * 2) + (((2 * s + hix) ^ u_swz<D>(qix)) << 4)));
+  }
 #pragma unroll
   for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(rf[s]));
-  asm volatile("s_barrier" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (every wave has its fragments out of stages 1 and 2: iteration 0 refills them)
 
   int jt_c = t_begin, g_c = 0;                       // this wave's tile: position inside the head, head
   auto next_tile = [&]() {
