@@ -27,6 +27,8 @@ namespace tfa {
 
 constexpr int VF_X4 = 1 << 22;            // this kernel
 constexpr int VF_X4_EPI = 1 << 23;        // 16-bit O leaves through a separate LDS region as whole rows (16-byte stores)
+constexpr int VF_X4_EPI_INPLACE = 1 << 30; // ... through the (idle) tile buffers instead: D = 256, whose five 32 KiB buffers fill the LDS.  A barrier
+                                          // behind the epilogue when another pass follows (its first DMA pieces land in other waves' slices)
 
 // ---- hand-owned accumulator registers -------------------------------------------------------------------------
 // O (row block rb, d tile d) lives in a[(rb*DT + d)*16 .. +15], the Q fragment (rb, k-slot ks) in a[128 + (rb*DS + ks)*4 .. +3].
@@ -149,7 +151,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   constexpr int PF = TFA_X4_PF;                    // fragment read-ahead, in fragments (= 2 MFMAs each)
   constexpr int NKB = 3;                           // K ring
   constexpr bool PAIR = CAUSAL && (VF & VF_PAIR);
-  constexpr bool EPI = (VF & VF_X4_EPI) != 0;
+  constexpr bool EPI_IN = (VF & VF_X4_EPI_INPLACE) != 0;
+  constexpr bool EPI = (VF & VF_X4_EPI) != 0 || EPI_IN;
+  static_assert(!EPI_IN || 4 * RB * 32 * D * 2 <= (NKB + 2) * 64 * D * 2, "in-place epilogue slices inside the tile buffers");
   static_assert(PPW >= 1 && PPW * NW == PIECES, "tile does not split into whole DMA pieces per wave");
   static_assert(PF >= 1 && PF <= NKF && PF <= NVF, "");
 
@@ -674,9 +678,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         typedef __attribute__((ext_vector_type(4))) T t4;
         int qix = qi, lanex = lane;                  // (through an empty asm: none of the addresses below may be hoisted out of the pass loop)
         asm volatile("" : "+v"(qix), "+v"(lanex));
-        char* const ow = smem + (NKB + 2) * TILE_BYTES + (wave * RB + rb) * (32 * D * 2);
+        char* const ow = smem + (EPI_IN ? 0 : (NKB + 2) * TILE_BYTES) + (wave * RB + rb) * (32 * D * 2);
         constexpr int CH = D / 8;                    // 16-byte chunks per row
-        const int osw = (CH == 16) ? (qix & 15) : (qix & 7);
+        const int osw = (CH >= 16) ? (qix & 15) : (qix & 7);
         static_for<0, DT * 4>([&](auto c_c) {
           constexpr int c = decltype(c_c)::value, R = (rb * DT + c / 4) * 16 + (c % 4) * 4;
           t4 v4 = {(T)(x4_o_read<R>() * inv), (T)(x4_o_read<R + 1>() * inv), (T)(x4_o_read<R + 2>() * inv), (T)(x4_o_read<R + 3>() * inv)};
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
 #pragma unroll
         for (int i = 0; i < 32 / RPI; ++i) {
           const int r = i * RPI + lanex / CH, cpos = lanex % CH;
-          const int c = cpos ^ ((CH == 16) ? (r & 15) : (r & 7));
+          const int c = cpos ^ ((CH >= 16) ? (r & 15) : (r & 7));
           u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
           __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 + rb * 32 + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, 2);   // nt: see tfa_fwd_kernel_il.h
         }
@@ -705,7 +709,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       }
     });
     // (the next pass's first DMA pieces land in the K/V buffers: every wave is past its last tile's reads — the last
-    //  iteration ended with a barrier — and the epilogue slices are private)
+    //  iteration ended with a barrier — and the epilogue slices are private; in place they lie IN those buffers: every wave's rows must be out)
+    if (EPI_IN && !F32OUT && pass + 1 < npass) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
   if (p.trace) {

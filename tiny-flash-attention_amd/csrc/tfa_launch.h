@@ -38,7 +38,7 @@ static const Variant kVariants[] = {
          "pass is requested before the heavy pass's O stores; a workgroup's first Q rows arrive through LDS)", 8,
      VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF2 | VF_IL_QLDS, 1},
     {32, "il4-pair-epi (4 waves x2 workgroups per CU; O leaves through the idle tile buffers as whole rows)", 4, VF_DMA | VF_IL | VF_PAIR | VF_IL_EPI | VF_IL_EPI_INPLACE, 1},
-    {34, "x4-d256-pair (the x4 kernel with ONE 32-row block per wave: head dims 136..256, 128-row workgroups, O stored directly)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR, 1},
+    {34, "x4-d256-pair (the x4 kernel with ONE 32-row block per wave: head dims 136..256, 128-row workgroups, O leaves through the idle tile buffers as whole rows)", 4, VF_DMA | VF_IL | VF_X4 | VF_PAIR, 1},
     {36, "il8-ksplit-epi (small grids: 8 waves on one 128-row block, waves 0-3 take the even KV tiles and waves 4-7 the odd ones, merged through LDS)", 8,
      VF_DMA | VF_IL | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
     {37, "il8-ksplit-pair-epi (the key-split kernel with causal blocks paired heavy+light per workgroup: two 128-row blocks per CU)", 8,

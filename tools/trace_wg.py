@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 from tiny_flash_attention_amd import _lib, ops  # noqa: E402
 
 CFG = {"cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096, 128, torch.bfloat16, False),
-       "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg2": (4, 8, 1024, 64, torch.float16, False)}
+       "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg2": (4, 8, 1024, 64, torch.float16, False),
+       "d256c": (4, 8, 4096, 256, torch.bfloat16, True), "d256": (4, 8, 4096, 256, torch.bfloat16, False)}
 
 
 def trace(variant, cfg):
