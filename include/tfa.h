@@ -285,7 +285,10 @@ int tfa_variant_available(int variant);
  * at dev_buf[8*workgroup_id ...]; the buffer must hold 64 B per workgroup (tfa_fwd_plan reports the
  * grid).  (t_end - t_start) / ticks * 100 MHz is the shader clock the workgroup actually ran at:
  * bench.py reports its median as the sustained clock next to the nominal 2.4 GHz.  NULL (default)
- * disables it. */
+ * disables it.  The stamps are written by a traced TWIN of the kernel (the kernels the library dispatches are compiled without the
+ * stamp code: its scalar state costs every workgroup ~130 register-lane moves): the main 16-bit-output instantiation of the il kernels
+ * (variants 30, 32, 36, 37), and the dma / x4 kernels; the special-case instantiations (windowed slices, decode-like idle waves, head
+ * dims below the kernel's width, fp32 output) leave the buffer untouched. */
 int tfa_debug_set_trace(void* dev_buf);
 /* Kernel bring-up flags of the calling thread (0 = normal).  128: the trace stamps describe a causal workgroup's SECOND
  * pass (the light block) instead of the first; 256: launch the windowed-descriptor instantiation (the one slices of
