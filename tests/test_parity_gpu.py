@@ -267,6 +267,25 @@ def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
         _lib.set_variant(-1)
 
 
+@pytest.mark.parametrize("variant", _avail([30, 32, 36, 37]))
+@pytest.mark.parametrize("B,H,Hk", [(2, 16, 4), (1, 8, 8), (1, 3, 3), (4, 6, 2), (1, 24, 8)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_work_item_decode_orders(tfa, oracle, dev, B, H, Hk, causal, variant):
+    # the il kernels decode (b, h, k/v head, work item) from the workgroup id with host-computed magic-number divisions, in one branch-free
+    # form for three dispatch orders (tfa_launch.h: fill_decode; KArgs::rr ..): GQA with (B * Hk) % 8 == 0 -> K/V heads round-robin over the
+    # XCDs with the G query heads of one side by side; B * H % 8 == 0 -> heads round-robin; else plain (b,h)-major.  Several blocks per
+    # head, so that every field of the decode matters; a wrong (b, h) reads another head's rows and fails the comparison outright.
+    from tiny_flash_attention_amd import _lib
+
+    _need_variant(variant, causal)
+    _lib.set_variant(variant)
+    try:
+        run_case(tfa, oracle, dev, torch.bfloat16, B, H, 768, 128, causal, Hk=Hk, seed=90 + B + H)
+        run_case(tfa, oracle, dev, torch.float16, B, H, 640, 64, causal, Hk=Hk, Nk=896, seed=91 + B + H)
+    finally:
+        _lib.set_variant(-1)
+
+
 # head dims: every multiple of 8 up to 128 runs on the 64- or 128-wide kernel with the columns beyond D read as zeros (the
 # LDS-DMA lanes and Q loads of those 16-byte chunks are pointed out of the buffer's range) and never stored.  The reference
 # dispatches D in {32, 64, 96, 128, ...} (flash_attention_cutlass/csrc/static_switch.h:39-66).
