@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 106 /* 0.1.6: + fp32 q,k,v (TFA_F32 input: the correctness path behind the reference's fp32 fixtures), variant numbers are ids (tfa_variant_available), tfa_bwd_workspace_bytes is 0 wherever the workspace would be ignored; 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
+#define TFA_VERSION 107 /* 0.1.7: tfa_bwd computes delta inside its dQ launch (tfa_debug_bwd_split bit 3 restores the separate launch), tfa_debug_set_trace is served by traced twins of the main kernels; 0.1.6: + fp32 q,k,v (TFA_F32 input: the correctness path behind the reference's fp32 fixtures), variant numbers are ids (tfa_variant_available), tfa_bwd_workspace_bytes is 0 wherever the workspace would be ignored; 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
 
 /* element types */
 enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1,
@@ -247,13 +247,15 @@ typedef struct tfa_bwd_params {
   int64_t workspace_bytes;
 } tfa_bwd_params;
 
-/* Launch the backward on `stream` (asynchronous): delta, dQ (S, dP, dQ: 3 GEMM units), then dK and dV in ONE launch that computes S and
- * dP once each (4 units; tfa_bwd_kv_kernel.h); with tfa_bwd_params::workspace: delta, dK/dV (which also writes dS), dQ = dS.K (1 unit).
+/* Launch the backward on `stream` (asynchronous): dQ (S, dP, dQ: 3 GEMM units; the launch also computes delta = rowsum(dO o O) for its rows
+ * and writes it to tfa_bwd_params::delta), then dK and dV in ONE launch that computes S and dP once each (4 units; tfa_bwd_kv_kernel.h);
+ * with tfa_bwd_params::workspace: delta (a launch of its own), dK/dV (which also writes dS), dQ = dS.K (1 unit).
  * Head dims 136..256: three single-gradient launches (dQ, dK, dV) of the 256-wide kernel, one wave per SIMD.
  * Deterministic: no atomics, fixed summation order. */
 int tfa_bwd(const tfa_bwd_params* p, void* stream);
 /* Debug / A-B (per thread): bit 0 makes tfa_bwd run dK and dV as two single-gradient launches (S computed twice: the form of
- * versions <= 0.1.4); bit 1 forces the windowed instantiations (the ones slices of 2 GiB and more get) on any problem. */
+ * versions <= 0.1.4); bit 1 forces the windowed instantiations (the ones slices of 2 GiB and more get) on any problem; bit 3 (value 8)
+ * computes delta by a launch of its own in front of the dQ launch (the form up to version 0.1.6) instead of inside it. */
 int tfa_debug_bwd_split(int on);
 /* Validate *p without launching (no GPU needed). */
 int tfa_bwd_plan(const tfa_bwd_params* p);

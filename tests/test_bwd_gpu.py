@@ -124,8 +124,10 @@ def test_bwd_strided_bnhd_matches_bhnd(tfa, oracle, dev, mode):
 
 
 def test_bwd_workspace_form_agrees_with_the_default(tfa, oracle, dev):
-    """dK and dV come from the same launch in both forms (bit-identical); dQ from the kept dS differs from the recomputing
-    launch only by P having been rounded to 16 bit before dS was formed: inside the (B1) bound, and deterministic."""
+    """dK and dV come from the same launch in both forms — on the same delta up to fp32 summation order (the default form computes delta inside
+    its dQ launch, the workspace form by a launch of its own: a last-bit difference of delta may move a 16-bit gradient by one ulp); dQ from
+    the kept dS differs from the recomputing launch only by P having been rounded to 16 bit before dS was formed: inside the (B1) bound,
+    and deterministic."""
     from tiny_flash_attention_amd import ops
 
     q, k, v = (t.to(dev) for t in oracle.make_inputs(2, 8, 1280, 128, torch.bfloat16, seed=21, Hk=4, Nk=1536))
@@ -136,7 +138,9 @@ def test_bwd_workspace_form_agrees_with_the_default(tfa, oracle, dev):
     g1 = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, 0.09, workspace=big)
     g2 = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, 0.09, workspace=big)
     torch.cuda.synchronize()
-    assert torch.equal(g0[1], g1[1]) and torch.equal(g0[2], g1[2])
+    assert torch.equal(g0[2], g1[2])                  # dV does not depend on delta
+    dkd = (g0[1].float() - g1[1].float()).abs()
+    assert bool((dkd <= 2.0 * ulp16(g0[1].float(), torch.bfloat16) + 1e-3 * g0[1].float().abs().max()).all()), dkd.max().item()
     for a, b in zip(g1, g2):
         assert torch.equal(a, b)
     d = (g0[0].float() - g1[0].float()).abs().max().item()
@@ -146,6 +150,41 @@ def test_bwd_workspace_form_agrees_with_the_default(tfa, oracle, dev):
     torch.cuda.synchronize()
     for a, b in zip(g0, g3):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,B,H,Hk,Nq,Nk,D,causal", [(torch.bfloat16, 2, 8, 4, 1000, 1280, 128, True), (torch.float16, 1, 4, 4, 777, 777, 64, False),
+                                                        (torch.bfloat16, 1, 2, 1, 300, 520, 256, True), (torch.float16, 1, 6, 2, 513, 513, 96, True)])
+def test_bwd_delta_inside_the_dq_launch(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal):
+    """tfa_bwd computes delta = rowsum(dO o O) inside its dQ launch (round 4: one launch and one pass over dO less); tfa_debug_bwd_split
+    bit 3 restores the launch of its own.  Same delta up to fp32 summation order, written to tfa_bwd_params::delta in both forms (every
+    row, ragged last block included); gradients within an ulp of each other."""
+    import ctypes as C
+    from tiny_flash_attention_amd import _lib, ops
+
+    q, k, v = (t.to(dev) for t in oracle.make_inputs(B, H, Nq, D, dtype, seed=33, Hk=Hk, Nk=Nk))
+    dout = make_dout(B, H, Nq, D, dtype, 34).to(dev)
+    sc = 1.0 / math.sqrt(D)
+    out, lse = ops.flash_attn_fwd(q, k, v, causal, sc)
+    res = []
+    for flag in (0, 8):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.full_like(lse, float("nan"))
+        pb = ops.make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, causal, sc)
+        _lib.debug_bwd_split(flag)
+        try:
+            _lib.check(_lib.lib().tfa_bwd(C.byref(pb), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+        finally:
+            _lib.debug_bwd_split(0)
+        res.append((dq, dk, dv, delta))
+    ref_delta = (dout.double() * out.double()).sum(-1)
+    for dq, dk, dv, delta in res:
+        assert bool(torch.isfinite(delta).all())
+        assert (delta.double() - ref_delta).abs().max().item() <= 1e-5 * max(1.0, ref_delta.abs().max().item())
+    assert (res[0][3] - res[1][3]).abs().max().item() <= 1e-5 * max(1.0, ref_delta.abs().max().item())
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert bool(((a.float() - b.float()).abs() <= 2.0 * ulp16(b.float(), dtype) + 1e-3 * b.float().abs().max()).all())   # (an ulp of the larger partial sums, where the result cancels)
+    assert torch.equal(res[0][2], res[1][2])          # dV does not depend on delta
 
 
 def test_bwd_deterministic_and_inputs_untouched(tfa, oracle, dev):

@@ -35,7 +35,7 @@ template <> hipError_t launch_delta<_Float16, 256>(const void*, const void*, flo
 
 namespace {
 
-thread_local int g_bwd_split = 0;   // tfa_debug_bwd_split: bit 0 = dK and dV as two launches (the round-1/2 form), bit 1 = force the windowed
+thread_local int g_bwd_split = 0;   // tfa_debug_bwd_split: bit 3 = delta by a launch of its own (not fused into the dQ launch), bit 0 = dK and dV as two launches (the round-1/2 form), bit 1 = force the windowed
                                     // (>= 2 GiB slices) instantiations on any problem; for A/B and parity cross-checks
 
 // extent of one (b,h) slice.  Kernels with one descriptor per slice need every byte offset they form (up to 512 rows past the end)
@@ -147,22 +147,6 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry, long long* ws_need 
     return (int)e;
   };
 
-  // delta = rowsum(dout o out)
-  {
-    const long long os[3] = {p->o_stride[0], p->o_stride[1], p->o_stride[2]};
-    const long long ds[3] = {p->do_stride[0], p->do_stride[1], p->do_stride[2]};
-    const long long rows = (long long)p->B * p->H * p->Nq;
-    hipError_t e;
-    if (p->dtype == TFA_BF16)
-      e = wide256 ? tfa::launch_delta<__bf16, 256>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
-          : wide  ? tfa::launch_delta<__bf16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
-                  : tfa::launch_delta<__bf16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry);
-    else
-      e = wide256 ? tfa::launch_delta<_Float16, 256>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
-          : wide  ? tfa::launch_delta<_Float16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
-                  : tfa::launch_delta<_Float16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry);
-    if (e != hipSuccess) return (int)e;
-  }
   // ---- with a workspace: dK/dV launch that also writes dS, then dQ = scale * dS . K (5 GEMM units) -----------------------------
   int nk_pad = 0, nq_pad = 0;
   const long long need = ws_bytes(p, &nk_pad, &nq_pad);
@@ -180,6 +164,29 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry, long long* ws_need 
   const bool ws_form = need > 0 && !(g_bwd_split & 1) && !wide256 && !big;
   if (ws_need) *ws_need = ws_form ? need : 0;
   const bool use_ws = p->workspace != nullptr && ws_form && ws_avail >= need;
+  // delta = rowsum(dout o out): the dQ launch computes it from its resident dO rows and the O rows and writes it for the launches behind it
+  // (BArgs::fuse_delta; 51 us and one pass over dO less at config 3) — unless the fused dK/dV launch runs FIRST (the workspace form), or
+  // tfa_debug_bwd_split bit 8 asks for the launch of its own (A/B, tests)
+  const bool fuse_delta = !use_ws && !(g_bwd_split & 8);
+  if (!fill(&a.out, p->out, p->o_stride, p->Nq, p->D, esz, bigp)) return TFA_ERR_STRIDE;
+  a.delta_w = p->delta;
+  a.fuse_delta = fuse_delta ? 1 : 0;
+  if (!fuse_delta)
+  {
+    const long long os[3] = {p->o_stride[0], p->o_stride[1], p->o_stride[2]};
+    const long long ds[3] = {p->do_stride[0], p->do_stride[1], p->do_stride[2]};
+    const long long rows = (long long)p->B * p->H * p->Nq;
+    hipError_t e;
+    if (p->dtype == TFA_BF16)
+      e = wide256 ? tfa::launch_delta<__bf16, 256>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
+          : wide  ? tfa::launch_delta<__bf16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
+                  : tfa::launch_delta<__bf16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry);
+    else
+      e = wide256 ? tfa::launch_delta<_Float16, 256>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
+          : wide  ? tfa::launch_delta<_Float16, 128>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry)
+                  : tfa::launch_delta<_Float16, 64>(p->out, p->dout, p->delta, os, ds, p->H, p->Nq, rows, p->D, s, dry);
+    if (e != hipSuccess) return (int)e;
+  }
   if (use_ws) {
     tfa::BArgs m = a;
     m.ws = p->workspace; m.ws_nk = nk_pad; m.ws_nq = nq_pad;
@@ -239,7 +246,7 @@ extern "C" {
 
 int tfa_bwd(const tfa_bwd_params* p, void* stream) { return run_bwd(p, stream, false); }
 int tfa_bwd_plan(const tfa_bwd_params* p) { return run_bwd(p, nullptr, true); }
-int tfa_debug_bwd_split(int on) { g_bwd_split = on & 7; return TFA_OK; }
+int tfa_debug_bwd_split(int on) { g_bwd_split = on & 15; return TFA_OK; }
 long long tfa_bwd_workspace_bytes(const tfa_bwd_params* p) {
   tfa_bwd_params q;
   if (!p) return TFA_ERR_NULL;

@@ -34,6 +34,9 @@ struct BTensor {
 
 struct BArgs {
   BTensor q, k, v, dout;
+  BTensor out;               // the forward's O: read by the dQ launch when it computes delta itself (fuse_delta)
+  float* delta_w;            // ... and writes it here (= delta) for the launches behind it
+  int fuse_delta;            // dQ launch: delta[b,h,i] = sum_d dO.O from its resident dO rows and the O rows, instead of a launch of its own (51 us at config 3)
   void* grad;                // output of this launch: dQ, dK or dV
   long long gs_b, gs_h, gs_n;
   unsigned g_bytes;
@@ -248,11 +251,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
       for (int s = 0; s < DS; ++s) r2f[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs2, (2 * s + hi) * 8 < p.dv ? off2 + s * 32 : (int)TFA_OOB, 0, 0));
     }
   }
+  // dQ, fuse_delta: this wave's O rows, for delta = rowsum(dO o O) (the dO rows are resident anyway): one launch and one pass over dO less
+  const bool fuse = MODE == BWD_DQ && p.fuse_delta != 0;
+  X8 of[MODE == BWD_DQ ? DS : 1];
+  if (MODE == BWD_DQ && fuse) {
+    const T* b3 = reinterpret_cast<const T*>(p.out.p) + b * p.out.s_b + hr * p.out.s_h;
+    auto rs3 = BIG ? rsrc_at(b3, p.out.full, (unsigned long long)r0 * (unsigned long long)p.out.s_n * 2ull) : __builtin_amdgcn_make_buffer_rsrc((void*)b3, 0, p.out.bytes, 0x00020000);
+    const int off3 = (my_row - (BIG ? r0 : 0)) * (int)p.out.s_n * 2 + hi * 16;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) of[s] = __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs3, (2 * s + hi) * 8 < p.dv ? off3 + s * 32 : (int)TFA_OOB, 0, 0));
+  }
   float lse2_lane = 0.f, delta_lane = 0.f;           // dQ: statistics of the lane's own query row
+  const long long stat_i = (long long)(b * p.H + hr) * p.Nq + my_row;
   if (!KEYS_RES && my_row < p.Nq) {
-    const long long si = (long long)(b * p.H + hr) * p.Nq + my_row;
-    lse2_lane = p.lse[si] * 1.4426950408889634f;
-    delta_lane = p.delta[si];
+    lse2_lane = p.lse[stat_i] * 1.4426950408889634f;
+    if (!fuse) delta_lane = p.delta[stat_i];
   }
 
   constexpr bool OWN_ACC = NW == 4;                  // head dims above 128: the accumulators are the hand-owned a[0:127] (tfa_acc_regs.h)
@@ -280,6 +293,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
 
   if (nu > 0) dma_issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (MODE == BWD_DQ && fuse) {
+    float d = 0.f;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) d = E::dot8(r2f[s], of[s], d);
+    d += __shfl_xor(d, 32, 64);                       // the row's other half of the columns
+    delta_lane = d;
+    if (hi == 0 && my_row < p.Nq) p.delta_w[stat_i] = d;
+  }
   // (one wave per SIMD, head dims above 128: the resident fragments live in AccVGPRs — the MFMAs read them there; pinned in
   //  architectural VGPRs hipcc parks them in AccVGPRs anyway and copies four dwords back in front of every MFMA)
 #pragma unroll
