@@ -25,6 +25,27 @@
 
 namespace tfa {
 
+// c + sum of the eight products a[e] * b[e], fp32 accumulation (v_dot2c_f32_bf16 / v_dot2c_f32_f16): delta inside the dQ launch
+template <typename T> struct Dot8;
+template <> struct Dot8<__bf16> {
+  static __device__ __forceinline__ float f(bf16x8 a, bf16x8 b, float c) {
+    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), c, false);
+    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), c, false);
+    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), c, false);
+    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), c, false);
+    return c;
+  }
+};
+template <> struct Dot8<_Float16> {
+  static __device__ __forceinline__ float f(f16x8 a, f16x8 b, float c) {
+    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), c, false);
+    return c;
+  }
+};
+
 struct BTensor {
   const void* p;
   long long s_b, s_h, s_n;   // strides in elements; unit stride along D
@@ -296,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
   if (MODE == BWD_DQ && fuse) {
     float d = 0.f;
 #pragma unroll
-    for (int s = 0; s < DS; ++s) d = E::dot8(r2f[s], of[s], d);
+    for (int s = 0; s < DS; ++s) d = Dot8<T>::f(r2f[s], of[s], d);
     d += __shfl_xor(d, 32, 64);                       // the row's other half of the columns
     delta_lane = d;
     if (hi == 0 && my_row < p.Nq) p.delta_w[stat_i] = d;

@@ -104,15 +104,6 @@ template <> struct Elem<__bf16> {
   static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
-  // c + sum of the eight products a[e] * b[e], fp32 accumulation (v_dot2c_f32_bf16)
-  static __device__ __forceinline__ float dot8(x8 a, x8 b, float c) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 x2;
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), c, false);
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), c, false);
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), c, false);
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), c, false);
-    return c;
-  }
   // c += a . b with the B operand read from AccVGPRs and the accumulator in architectural VGPRs — for kernels whose register
   // budget is "accumulators and resident operands in AccVGPRs, everything VALU touches in VGPRs" (one wave per SIMD, 512
   // registers).  hipcc picks ONE form for every MFMA of a kernel; with the builtin the VALU-consumed accumulators land in AccVGPRs
@@ -128,14 +119,6 @@ template <> struct Elem<__bf16> {
 static __device__ __forceinline__ void mfma_drain(f32x16& c) { asm volatile("s_nop 12" : "+v"(c)); }
 template <> struct Elem<_Float16> {
   using x8 = f16x8;
-  static __device__ __forceinline__ float dot8(x8 a, x8 b, float c) {
-    typedef __attribute__((ext_vector_type(2))) _Float16 x2;
-    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), c, false);
-    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), c, false);
-    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), c, false);
-    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), c, false);
-    return c;
-  }
   static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
