@@ -299,6 +299,11 @@ int tfa_debug_set_trace(void* dev_buf);
  * line on the caller's stream instead of forking them over the thread's side streams; the low bits insert fences / force the burst path in the x4 kernel
  * (tfa_fwd_kernel_x4.h) and are only meaningful to tools/. */
 int tfa_debug_set_flags(int flags);
+/* Host-side check of the kernels' work-item decode (no GPU needed): decodes workgroup `id` of a launch with the given batch, query
+ * heads, K/V heads and work items per head exactly as the il kernels do on the device — the host-computed magic-number divisions
+ * (tfa_launch.h: fill_decode, tfa_fwd_kernel.h: FastDiv) applied in the kernels' branch-free form — and writes {b, h, hk, wi} to
+ * out[0..3].  tests/test_abi.py compares it with the plain divisions of the three dispatch orders. */
+int tfa_debug_decode(int B, int H, int Hk, int nwork, int id, int* out);
 
 /* Algorithmic work of *p: flops = 4*B*H*Nq*Nk*D (x1/2 when causal, the reference's
  * convention) and bytes = Q+K+V read once + O written once (+LSE). */

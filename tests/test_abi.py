@@ -486,3 +486,46 @@ def test_assembly_audit_tools_flag_what_they_exist_for(tmp_path):
     assert r.returncode == 0 and "MFMA hazards: 0" in r.stdout, r.stdout
     assert len(subprocess.run(["bash", ag, str(bad)], capture_output=True, text=True).stdout.strip().splitlines()) == 1
     assert subprocess.run(["bash", ag, str(good)], capture_output=True, text=True).stdout.strip() == ""
+
+
+def test_work_item_decode_matches_plain_divisions():
+    """the il kernels decode (b, h, k/v head, work item) from the workgroup id with host-computed magic-number divisions in one branch-free
+    form (tfa_launch.h: fill_decode); tfa_debug_decode evaluates exactly that on the host.  Against the three dispatch orders written with
+    plain divisions (GQA with (B * Hk) % 8 == 0: K/V heads round-robin over the XCDs; B * H % 8 == 0: heads round-robin; else (b,h)-major)."""
+    import ctypes as C
+    import itertools
+    from tiny_flash_attention_amd import _lib
+
+    L = _lib.lib()
+    L.tfa_debug_decode.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)]
+    out = (C.c_int * 4)()
+
+    def plain(id, B, H, Hk, nwork):
+        G = H // Hk
+        if G > 1 and (B * Hk) % 8 == 0:
+            x, s = id & 7, id >> 3
+            per = G * nwork
+            kg, r = x + 8 * (s // per), s % per
+            bh, wi = (kg // Hk) * H + (kg % Hk) * G + r // nwork, r % nwork
+        elif (B * H) % 8 == 0:
+            x, s = id & 7, id >> 3
+            bh, wi = x + 8 * (s // nwork), s % nwork
+        else:
+            bh, wi = id // nwork, id % nwork
+        b, h = bh // H, bh % H
+        return b, h, h // G, wi
+
+    n = 0
+    for B, H, Hk, nwork in itertools.product([1, 2, 3, 8, 13], [1, 2, 6, 8, 32, 40], [1, 2, 8], [1, 2, 3, 8, 17, 64]):
+        if H % Hk:
+            continue
+        grid = B * H * nwork
+        for id in list(range(min(grid, 300))) + [grid - 1, grid // 2]:
+            assert L.tfa_debug_decode(B, H, Hk, nwork, id, out) == 0
+            assert tuple(out) == plain(id, B, H, Hk, nwork), (B, H, Hk, nwork, id)
+            n += 1
+    # large operands: the magic numbers are exact for every dividend below 2^31
+    for B, H, Hk, nwork, id in [(1, 1, 1, 1, 2**31 - 2), (64, 128, 8, 999, 64 * 128 * 999 - 1), (7, 33, 11, 12345, 7 * 33 * 12345 - 1), (8, 96, 8, 2731, 8 * 96 * 2731 - 5)]:
+        assert L.tfa_debug_decode(B, H, Hk, nwork, id, out) == 0
+        assert tuple(out) == plain(id, B, H, Hk, nwork)
+    assert n > 10000

@@ -26,6 +26,7 @@ SYMBOLS = (
     "tfa_fwd_work",
     "tfa_debug_set_trace",
     "tfa_debug_set_flags",
+    "tfa_debug_decode",
     "tfa_merge",
     "tfa_fwd_splitkv",
     "tfa_fwd_splitkv_workspace",

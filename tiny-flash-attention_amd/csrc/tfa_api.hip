@@ -566,6 +566,24 @@ int tfa_set_variant(int variant) {
 }
 int tfa_get_variant(void) { return g_variant; }
 int tfa_debug_set_flags(int flags) { g_dbg_flags = flags; return TFA_OK; }
+int tfa_debug_decode(int B, int H, int Hk, int nwork, int id, int* out) {
+  if (!out || B < 1 || H < 1 || Hk < 1 || nwork < 1 || id < 0 || H % Hk) return TFA_ERR_SHAPE;
+  tfa::KArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.H = H; a.Hk = Hk; a.nwork = nwork; a.nbh = B * H;
+  tfa::fill_decode(&a);
+  // the device code of tfa_fwd_kernel_il.h, on the host (fd_div is a device function: its formula here)
+  auto div = [](int n, tfa::FastDiv f) { return (int)(((unsigned)(((unsigned long long)(unsigned)n * f.m) >> 32) + (unsigned)n) >> f.l); };
+  const int x = a.rr ? (id & 7) : 0, s = a.rr ? (id >> 3) : id;
+  const int sq = div(s, a.fd_wa), r = s - sq * a.wa;
+  const int kg = a.rr ? x + 8 * sq : sq;
+  const int rq = div(r, a.fd_nwork);
+  out[3] = r - rq * a.nwork;
+  out[0] = div(kg, a.fd_wd);
+  out[1] = (kg - out[0] * a.wd) * a.wg + rq;
+  out[2] = div(out[1], a.fd_g);
+  return TFA_OK;
+}
 int tfa_debug_set_trace(void* dev_buf) { g_trace = reinterpret_cast<unsigned long long*>(dev_buf); return TFA_OK; }
 int tfa_num_variants(void) { return tfa::kNumVariants; }
 int tfa_variant_available(int variant) { return tfa::variant_built(variant) ? 1 : 0; }
