@@ -131,6 +131,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // The two waves of a SIMD run the burst-structured tile body (GEMM-I, element-wise, GEMM-II) in step behind the tile barrier: matrix bursts collide,
+  // element-wise bursts leave the pipe idle.  A static issue priority for the younger wave (role 1 in the fused launch) lets it win the first
+  // burst and pulls the two out of step: +0.3 .. +0.8 percent at D = 128 over five shapes, -2.6 percent at D = 64 (profiles/r04b_bwd_priority_ab.txt)
+  if (D == 128 && NW == 8 && (wave >= NW / 2)) asm volatile("s_setprio 2" ::: "memory");
   const int qi = lane & 31;
   const int hi = lane >> 5;
 

@@ -66,6 +66,10 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kg = wave % KG;                        // key group: rows r0 + 32*kg ..
   const int role = wave / KG;                      // 0: S, P, dV     1: dP, dS, dK
+  // The two waves of a SIMD run the burst-structured tile body (GEMM-I, element-wise, GEMM-II) in step behind the tile barrier: matrix bursts collide,
+  // element-wise bursts leave the pipe idle.  A static issue priority for the younger wave (role 1 in the fused launch) lets it win the first
+  // burst and pulls the two out of step: +0.3 .. +0.8 percent at D = 128 over five shapes, -2.6 percent at D = 64 (profiles/r04b_bwd_priority_ab.txt)
+  if (D == 128 && (role == 1)) asm volatile("s_setprio 2" ::: "memory");
   const int qi = lane & 31;
   const int hi = lane >> 5;
 
