@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 107 /* 0.1.7: tfa_bwd computes delta inside its dQ launch (tfa_debug_bwd_split bit 3 restores the separate launch), tfa_debug_set_trace is served by traced twins of the main kernels; 0.1.6: + fp32 q,k,v (TFA_F32 input: the correctness path behind the reference's fp32 fixtures), variant numbers are ids (tfa_variant_available), tfa_bwd_workspace_bytes is 0 wherever the workspace would be ignored; 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
+#define TFA_VERSION 108 /* 0.1.8: TFA_FWD_EXACT_MAX runs the il8 kernel's exact-max instantiation (variant 38) on grids that fill the chip; 0.1.7: tfa_bwd computes delta inside its dQ launch (tfa_debug_bwd_split bit 3 restores the separate launch), tfa_debug_set_trace is served by traced twins of the main kernels; 0.1.6: + fp32 q,k,v (TFA_F32 input: the correctness path behind the reference's fp32 fixtures), variant numbers are ids (tfa_variant_available), tfa_bwd_workspace_bytes is 0 wherever the workspace would be ignored; 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
 
 /* element types */
 enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1,
@@ -120,9 +120,12 @@ typedef struct tfa_fwd_params {
  * TFA_FWD_EXACT_MAX: round P to 16 bits at the REFERENCE's points — every KV tile is exponentiated against the exact running
  *   row maximum, as flash_attention_cutlass/csrc/flash_attention.cu:263-316 and flash_attention_py/main_torch_only.py:240-260
  *   do — instead of the default kernels' lazily re-based row reference (same mathematics, O and LSE agree to the P-rounding
- *   bound, but the 16-bit roundings of P fall elsewhere).  Runs the burst-structured LDS-DMA kernel: head dims up to 128,
- *   (b,h) slices below 2 GiB, no GQA row packing; 10-15 % slower than the default on large grids.  For callers that compare
- *   against the reference element by element (rtol 1e-3 with fp32 output).
+ *   bound, but the 16-bit roundings of P fall elsewhere).  Head dims up to 128, (b,h) slices below 2 GiB, no GQA row packing.  Where the
+ *   default would run the il8 kernel (grids that fill the chip: the BASELINE configs 3, 4, 5) the flag runs that kernel's exact-max
+ *   instantiation ("exact-il8", variant 38, round 5: the same issue-interleaved tile body; a tile in which some row of a wave saw a new
+ *   maximum also multiplies O by exp2(old - new) behind its QK^T MFMAs) — 8-9 % slower than the default, `secondary.cfg3_exact_max` in
+ *   bench.py's line; everywhere else the burst-structured LDS-DMA kernel (variant 17; 10-15 % slower than the default).  For callers
+ *   that compare against the reference element by element (rtol 1e-3 with fp32 output).
  *
  * WHICH TOLERANCE EACH PATH GUARANTEES (stated and asserted in tests/test_parity_gpu.py; A[i,d] = sum_j P_ij |v_jd| is the
  * non-cancelling magnitude of an output element, eps16 = 2^-8 for bf16, 2^-11 for fp16):
@@ -134,7 +137,7 @@ typedef struct tfa_fwd_params {
  *   TFA_FWD_EXACT_MAX, fp32 output vs the reference's own tile loop (main_torch_only.py:160-270), element by element:
  *                                                              |d| <= 1e-3 * |ref|  wherever |ref| is not a cancelling sum — BASELINE.json's rtol=1e-3,
  *                                                              checked on whole heads of BASELINE configs 3 and 4; measured cost in bench.py's
- *                                                              `secondary.cfg3_exact_max` (0.60 vs 0.52 ms on the headline shape). */
+ *                                                              `secondary.cfg3_exact_max` (0.54-0.56 vs 0.49-0.51 ms on the headline shape: profiles/r05_exact_il8.txt). */
 #define TFA_FWD_EXACT_MAX 1
 
 /* Library version (TFA_VERSION of the build). */

@@ -88,9 +88,9 @@ def test_product_build_rejects_ab_arms():
     # the product library carries the dispatched kernels only (tfa_launch.h); the other table entries answer TFA_ERR_VARIANT
     L = _lib.lib()
     avail = [v for v in range(_lib.num_variants()) if _lib.variant_available(v)]
-    for v in (17, 30, 32, 34, 36, 37):
+    for v in (17, 30, 32, 34, 36, 37, 38):
         assert v in avail
-    assert len(avail) == 6 or len(avail) == _lib.num_variants()      # (make EXPERIMENTAL=1 builds carry every arm)
+    assert len(avail) == 7 or len(avail) == _lib.num_variants()      # (make EXPERIMENTAL=1 builds carry every arm)
     for v in range(_lib.num_variants()):
         if v not in avail:
             assert L.tfa_set_variant(v) == -7
@@ -192,8 +192,11 @@ def test_exact_max_flag_selects_the_exact_running_max_kernel():
     assert _lib.variant_name(L.tfa_fwd_variant(C.byref(p))).startswith("il8")
     p.flags = _lib.TFA_FWD_EXACT_MAX
     v = L.tfa_fwd_variant(C.byref(p))
-    assert v == 17 and not _lib.lazy_reference(v)
+    assert v == 38 and not _lib.lazy_reference(v)                  # the headline grid: the il8 kernel's exact-max instantiation (round 5)
     assert L.tfa_fwd_suggest_splits(C.byref(p)) == 1
+    s = _params(B=1, H=4, Hk=4, Nq=1024, Nk=1024)                   # a small grid: the burst-structured LDS-DMA kernel, as before
+    s.flags = _lib.TFA_FWD_EXACT_MAX
+    assert L.tfa_fwd_variant(C.byref(s)) == 17 and not _lib.lazy_reference(17)
     g = _params(B=64, H=32, Hk=8, Nq=1, Nk=8192)
     g.flags = _lib.TFA_FWD_EXACT_MAX
     assert plan(g)[1] == 64 * 32                                   # no GQA row packing under the flag

@@ -144,16 +144,16 @@ def _avail(variants):
     return [v for v in variants if v < 0 or _lib.variant_available(v)]
 
 
-PRODUCT_VARIANTS = (17, 30, 32, 34, 36, 37)     # tfa_launch.h: kVariants — the six kernels the library dispatches
+PRODUCT_VARIANTS = (17, 30, 32, 34, 36, 37, 38)     # tfa_launch.h: kVariants — the seven kernels the library dispatches (38: round 5, exact-il8)
 
 
 def _built_variants():
     """Every kernel variant THIS build of the library carries and that serves head dims 64 / 128 with correct results: the product
     kernels (minus the 256-wide one, whose shapes live in test_head_dims_*), plus — `make EXPERIMENTAL=1` builds only — the A/B arms
-    of rounds 1-3 (the round-4 arms 38..54 exist 128 wide only: tools/r4_bits.py; 55..60 are timing-only ablations)."""
+    of rounds 1-3 (the round-4 arms were a patch of their own; 38 is round 5's exact-il8, a product kernel)."""
     from tiny_flash_attention_amd import _lib
 
-    return [v for v in range(_lib.num_variants()) if _lib.variant_available(v) and v != 34 and v < 38]
+    return [v for v in range(_lib.num_variants()) if _lib.variant_available(v) and v != 34 and v <= 38]
 
 
 def test_product_kernels_are_in_the_build(tfa):
@@ -197,10 +197,24 @@ def test_exact_running_max_flag(tfa, oracle, dev, dtype, B, H, Hk, N, Nk, D, cau
     out16, lse = ops.flash_attn_fwd(qd, kd, vd, causal, sc, exact_max=True)
     out32, _ = ops.flash_attn_fwd(qd, kd, vd, causal, sc, out_f32=True, exact_max=True)
     torch.cuda.synchronize()
-    assert not _lib.lazy_reference(17)
+    assert not _lib.lazy_reference(17) and not _lib.lazy_reference(38)
     _lib.set_variant(17)          # (check() must not assume GQA row packing: a forced variant says "as given", like the flag)
     try:
         check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype, var=17)
+    finally:
+        _lib.set_variant(-1)
+    # ... and the il8 instantiation the flag selects on grids that fill the chip (variant 38, round 5), forced onto the same problem
+    _lib.set_variant(38)
+    try:
+        o16x, lsex = ops.flash_attn_fwd(qd, kd, vd, causal, sc)
+        o32x, _ = ops.flash_attn_fwd(qd, kd, vd, causal, sc, out_f32=True)
+        torch.cuda.synchronize()
+        check(oracle, o16x, o32x, lsex, q, k, v, causal, sc, dtype, var=38)
+        emu = oracle.tiled_emulation(q, k, v, causal, sc, 64)
+        A = oracle.abs_weighted(q, k, v, causal, sc)
+        big = emu.abs() > 0.05 * A
+        rel = ((o32x.cpu() - emu).abs() / emu.abs().clamp_min(1e-30))[big]
+        assert (rel > 1e-3).float().mean().item() <= 1e-4, f"exact-il8: rtol 1e-3 exceeded by {(rel > 1e-3).float().mean().item():.2e} of the elements"
     finally:
         _lib.set_variant(-1)
     # and, plainly: rtol 1e-3 against the reference's rounding points wherever the output is not cancelling to ~0
@@ -233,6 +247,8 @@ def test_exact_running_max_flag_at_baseline_sizes(tfa, oracle, dev, cfg, B, H, N
     out32, lse = ops.flash_attn_fwd(q, k, v, causal, sc, out_f32=True, exact_max=True)
     out16, _ = ops.flash_attn_fwd(q, k, v, causal, sc, exact_max=True)
     torch.cuda.synchronize()
+    from tiny_flash_attention_amd import _lib
+    assert _lib.variant_for(B, H, H, N, N, D, causal, flags=_lib.TFA_FWD_EXACT_MAX) == 38      # the il8 kernel's exact-max instantiation serves these grids
     assert bool(torch.isfinite(out32).all())
     for (b, h) in heads:
         sl = lambda t: t[b:b + 1, h:h + 1].cpu()
@@ -250,7 +266,7 @@ def test_exact_running_max_flag_at_baseline_sizes(tfa, oracle, dev, cfg, B, H, N
         assert (sl(out16).float() - emu).abs().max().item() <= 1e-2
 
 
-@pytest.mark.parametrize("variant", _avail([-1, 17, 30, 31, 33, 35, 36, 37]))     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
+@pytest.mark.parametrize("variant", _avail([-1, 17, 30, 31, 33, 35, 36, 37, 38]))     # automatic (small grid: il4-epi), the burst kernel and the 8-wave il kernels forced
 @pytest.mark.parametrize("Nq,Nk,causal", [(128, 384, True), (384, 128, True), (100, 333, False), (1, 1000, True), (257, 64, False),
                                           (700, 1500, True), (1111, 1111, False)])
 def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
@@ -267,7 +283,7 @@ def test_gqa_and_ragged_nq_nk(tfa, oracle, dev, Nq, Nk, causal, variant):
         _lib.set_variant(-1)
 
 
-@pytest.mark.parametrize("variant", _avail([30, 32, 36, 37]))
+@pytest.mark.parametrize("variant", _avail([30, 32, 36, 37, 38]))
 @pytest.mark.parametrize("B,H,Hk", [(2, 16, 4), (1, 8, 8), (1, 3, 3), (4, 6, 2), (1, 24, 8)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_work_item_decode_orders(tfa, oracle, dev, B, H, Hk, causal, variant):
@@ -289,7 +305,7 @@ def test_work_item_decode_orders(tfa, oracle, dev, B, H, Hk, causal, variant):
 # head dims: every multiple of 8 up to 128 runs on the 64- or 128-wide kernel with the columns beyond D read as zeros (the
 # LDS-DMA lanes and Q loads of those 16-byte chunks are pointed out of the buffer's range) and never stored.  The reference
 # dispatches D in {32, 64, 96, 128, ...} (flash_attention_cutlass/csrc/static_switch.h:39-66).
-@pytest.mark.parametrize("variant", _avail([-1, 17, 30, 33]))
+@pytest.mark.parametrize("variant", _avail([-1, 17, 30, 33, 38]))
 @pytest.mark.parametrize("dtype,B,H,N,D,causal", [
     (torch.bfloat16, 2, 3, 384, 96, True),
     (torch.float16, 1, 4, 512, 32, False),
@@ -446,7 +462,7 @@ def test_inputs_not_modified_and_deterministic(tfa, oracle, dev):
 # ---------------------------------------------------------------------------------------------
 # data-dependent branch: the exact "max unchanged -> skip the O rescale" path and late max jumps
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", _avail([1, 2, 5, 10, 11, 14, 15, 17, 18, 19, 20, 22, 26, 27, 28, 30, 31, 32, 33, 35]))
+@pytest.mark.parametrize("variant", _avail([1, 2, 5, 10, 11, 14, 15, 17, 18, 19, 20, 22, 26, 27, 28, 30, 31, 32, 33, 35, 38]))
 def test_late_max_jump_spike(tfa, oracle, dev, variant):
     from tiny_flash_attention_amd import _lib, ops
 
@@ -684,7 +700,7 @@ def test_long_context_cfg4_properties(tfa, dev):
     assert (out_k.float() - out[:, :2].float()).abs().max().item() <= 1e-2 * out.float().abs().max().item() + 2 ** -9
 
 
-@pytest.mark.parametrize("variant", _avail([-1, 27, 30, 33]))
+@pytest.mark.parametrize("variant", _avail([-1, 27, 30, 33, 38]))
 def test_strided_bnhd_matches_bhnd(tfa, oracle, dev, variant):
     from tiny_flash_attention_amd import _lib, ops
 

@@ -223,7 +223,7 @@ def variant_name(v):
     return lib().tfa_variant_name(int(v)).decode()
 
 
-def variant_for(B, H, Hk, Nq, Nk, D, is_causal, dtype=TFA_BF16):
+def variant_for(B, H, Hk, Nq, Nk, D, is_causal, dtype=TFA_BF16, flags=0):
     """The variant tfa_fwd would run for a contiguous (B,H,N,D) problem of these sizes (no GPU needed)."""
     p = TfaFwdParams()
     p.q = p.k = p.v = p.out = 0x1000           # never dereferenced: tfa_fwd_variant only validates and plans
@@ -235,6 +235,7 @@ def variant_for(B, H, Hk, Nq, Nk, D, is_causal, dtype=TFA_BF16):
     p.softmax_scale = 1.0
     p.is_causal = 1 if is_causal else 0
     p.dtype = p.out_dtype = dtype
+    p.flags = flags
     v = lib().tfa_fwd_variant(C.byref(p))
     if v < 0:
         check(v)
@@ -242,5 +243,6 @@ def variant_for(B, H, Hk, Nq, Nk, D, is_causal, dtype=TFA_BF16):
 
 
 def lazy_reference(v):
-    """True for the variants that keep a lazily re-based row reference instead of the exact running max."""
+    """True for the variants that keep a lazily re-based row reference instead of the exact running max (names "il..." / "x4...";
+    "exact-il8", variant 38, is the il8 kernel with the exact running max)."""
     return variant_name(v).startswith("il") or variant_name(v).startswith("x4")

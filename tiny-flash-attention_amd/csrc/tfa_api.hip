@@ -41,8 +41,14 @@ bool one_descriptor(const tfa_fwd_params* p) {
 int pick_variant(const tfa_fwd_params* p) {
   if (p && p->D > 128) return tfa::kX4D256Variant;   // one kernel serves 136..256 (a forced variant does not apply)
   if (g_variant >= 0) return g_variant;
-  if (p && (p->flags & TFA_FWD_EXACT_MAX)) return tfa::kSplitVariant;   // the LDS-DMA kernel keeps the exact running max (validate: D <= 128)
   if (!p) return tfa::kDefaultVariant;
+  if (p->flags & TFA_FWD_EXACT_MAX) {
+    // the exact running max (validate: D <= 128): where the default would run il8 — grids that fill the chip, whole 256-row blocks' worth of
+    // rows, slices below 2 GiB — its exact-max instantiation (round 5); everywhere else the burst-structured LDS-DMA kernel
+    tfa_fwd_params d = *p;
+    d.flags &= ~TFA_FWD_EXACT_MAX;
+    return (pick_variant(&d) == tfa::kDefaultVariant && one_descriptor(p) && p->Nq > 256 - 32) ? tfa::kExactVariant : tfa::kSplitVariant;
+  }
   // Measured on MI355X (tests/tools/ab.py, profiles/): 256-row query blocks (8 waves) are fastest when there
   // are enough of them to fill 256 CUs and no causal diagonal; 128-row blocks (two 4-wave workgroups per
   // CU) waste less of the causal diagonal and fill the chip on small problems (BASELINE config 2:

@@ -51,6 +51,22 @@ template <int DT> static __device__ __forceinline__ void o_scale(float alpha) {
   if constexpr (DT > 2)
     asm volatile(".irp r," TFA_O_LIST23 "\n\tv_mul_f32 v[\\r], v[\\r], %0\n\t.endr" ::"v"(alpha) : TFA_O_CLOB2, TFA_O_CLOB3);
 }
+// (two v_pk_mul_f32 per quad instead: -5 %, profiles/r05_exact_il8.txt — packed fp32 forms do not run in an MFMA's shadow)
+// O registers 192 + 4 Q .. 192 + 4 Q + 3 *= alpha: the exact-max body's share of the re-base behind QK^T MFMA Q (the PV MFMAs that wrote O are a tile
+// barrier away; the next ones that read it as C are >= one MFMA slot behind the last of these: tools/audit_mfma_hazard.py checks both at build time)
+template <int Q> static __device__ __forceinline__ void o_scale4(float alpha) {
+  asm volatile("v_mul_f32 v[192+4*%1], v[192+4*%1], %0\n\tv_mul_f32 v[193+4*%1], v[193+4*%1], %0\n\t"
+               "v_mul_f32 v[194+4*%1], v[194+4*%1], %0\n\tv_mul_f32 v[195+4*%1], v[195+4*%1], %0" ::"v"(alpha), "n"(Q)
+               : TFA_O_CLOB0, TFA_O_CLOB1, TFA_O_CLOB2, TFA_O_CLOB3);
+}
+static __device__ __forceinline__ void o_scale4_d(int q, float alpha) {   // q folds to a constant
+  switch (q) {
+    case 0: o_scale4<0>(alpha); break; case 1: o_scale4<1>(alpha); break; case 2: o_scale4<2>(alpha); break; case 3: o_scale4<3>(alpha); break;
+    case 4: o_scale4<4>(alpha); break; case 5: o_scale4<5>(alpha); break; case 6: o_scale4<6>(alpha); break; case 7: o_scale4<7>(alpha); break;
+    case 8: o_scale4<8>(alpha); break; case 9: o_scale4<9>(alpha); break; case 10: o_scale4<10>(alpha); break; case 11: o_scale4<11>(alpha); break;
+    case 12: o_scale4<12>(alpha); break; case 13: o_scale4<13>(alpha); break; case 14: o_scale4<14>(alpha); break; default: o_scale4<15>(alpha); break;
+  }
+}
 // out[r] = O[d tile DI][r] * inv
 #define TFA_OR(B, K) "v_mul_f32 %" #K ", v[" #B "+" #K "], %16\n\t"
 #define TFA_OREAD_CASE(DI, B)                                                                                          \

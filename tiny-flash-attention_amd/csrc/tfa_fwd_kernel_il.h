@@ -60,11 +60,30 @@ constexpr int VF_IL_PREF2 = 1 << 29;     // paired causal blocks: the light pass
 constexpr int VF_IL_QLDS = 1 << 28;      // the FIRST prologue of a workgroup brings Q in through LDS: a wave's 32 rows by LDS-DMA into its slice of the (idle)
                                          // epilogue region — whole 1 KiB pieces, 64 cache lines per wave instead of 256 32-byte segments — and the eight
                                          // fragments back with ds_read_b128 (the K tile's swizzle).  Later passes load Q as before (registers, PREF2)
+constexpr int VF_IL_EXACT = 1 << 30;     // the reference's rounding points (TFA_FWD_EXACT_MAX): every tile is exponentiated against the EXACT running row maximum
+                                         // (flash_attention.cu:263-316, main_torch_only.py:240-260) instead of the lazily re-based reference below.  Same
+                                         // issue-interleaved body; a tile in which some row of the wave saw a new maximum runs the instantiation of the body
+                                         // that also multiplies O by exp2(old - new): 64 v_mul, four behind each QK^T MFMA (round 5)
 constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of the waves issues its pieces behind the first PV MFMAs,
                                          // so the two waves of a SIMD never sit in an LDS-DMA issue stall at the same time
 
 }  // namespace tfa
 #include "tfa_fwd_il_regs.h"
+
+// Timing probe (never in the product build): -DTFA_IL_PAD=n -DTFA_IL_PADKIND=k puts n extra do-nothing instructions behind every MFMA of the
+// fast path — k = 0 s_nop 0, 1 SALU (s_mov_b32 to a dead register), 2 VALU (v_mov_b32 to a dead register), 3 s_waitcnt with counts nothing reaches.
+// The slope d(time)/d(instructions) per class is what an instruction diet of the tile body can buy (tools/r5_pad.sh, profiles/r05_pad_slope.txt)
+#if defined(TFA_IL_PAD)
+#define TFA_IL_PAD1_0 asm volatile("s_nop 0");
+#define TFA_IL_PAD1_1 { int pad_s_; asm volatile("s_mov_b32 %0, 0" : "=s"(pad_s_)); }
+#define TFA_IL_PAD1_2 { int pad_v_; asm volatile("v_mov_b32 %0, 0" : "=v"(pad_v_)); }
+#define TFA_IL_PAD1_3 asm volatile("s_waitcnt vmcnt(63) lgkmcnt(15)");
+#define TFA_IL_PADCAT_(k) TFA_IL_PAD1_##k
+#define TFA_IL_PADCAT(k) TFA_IL_PADCAT_(k)
+#define TFA_IL_PAD_HERE { _Pragma("unroll") for (int pad_i_ = 0; pad_i_ < TFA_IL_PAD; ++pad_i_) TFA_IL_PADCAT(TFA_IL_PADKIND) }
+#else
+#define TFA_IL_PAD_HERE
+#endif
 
 namespace tfa {
 
@@ -106,6 +125,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   // MFMA slot (0..N1+N2-1) in which softmax element e (0..31) is summed and packed; its exp2 is issued one slot and its
   // scale/subtract two slots earlier.  P slot s (elements 8s..8s+7) feeds PV MFMAs N1+DT*s.., so it must be packed in
   // an EARLIER slot than N1+DT*s (also the distance the asm MFMA needs after a VALU write of its operand).
+  // (the body that also re-bases O — VF_IL_EXACT — carries 4 v_mul per MFMA in part 1 on top; moving elements behind the PV MFMAs to even the two parts
+  //  out — 10, 12 or 14 elements in part 1 — measured +-0.4 %, like every other placement question here: the VALU total is what counts, round 5)
   auto slot_of_elem = [](int e) constexpr -> int {
     return 1 + (e < NE1 ? e * N1 / NE1 : N1 + (e - NE1) * (3 * DT - 1) / (32 - NE1));
   };
@@ -261,6 +282,7 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   constexpr bool EPI = (VF & VF_IL_EPI) != 0;
   constexpr bool PREF2 = PAIR && (VF & VF_IL_PREF2) != 0;
   constexpr bool QLDS = (VF & VF_IL_QLDS) != 0;
+  constexpr bool EXACT = (VF & VF_IL_EXACT) != 0;
   static_assert(!QLDS || ((VF & VF_IL_EPI) && !(VF & (VF_IL_EPI_INPLACE | VF_IL_KSPLIT | VF_IL_WINDOWED | VF_IL_IDLE | VF_IL_SEAM))), "QLDS: a wave-private slice of the separate epilogue region");
   // store instructions of O per pass and wave (the epilogue's three forms: fp32 direct, 16-bit rows through LDS, 16-bit direct)
   constexpr int NST_EPI = F32OUT ? 4 * DT : ((VF & VF_IL_EPI) ? 32 / (64 / (D / 8)) : 4 * DT);
@@ -443,7 +465,25 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     auto trigger = [&](float mloc) -> bool { return __any(mloc * sc > mref + 8.f); };
     // (mloc may be the max over only this half-wave's 32 keys of the tile: the trigger is an OR over all lanes anyway;
     //  the re-base itself combines the two halves first so that both lanes of a row keep the same reference)
+    // EXACT: the running maximum itself is the reference — nref = max(mref, tile max) for every row, every tile; rows whose maximum did not
+    // move get alpha = exp2(0) = 1 (the multiplication is the identity), and a wave none of whose rows moved skips it
+    auto exact_step = [&](float mloc, float& alpha) -> bool {
+      const float x = pair_max(mloc) * sc;
+      const float nref = fmaxf(mref, x);
+      const bool moved = __any(nref != mref);
+      alpha = fast_exp2(mref - nref);
+      mref = nref;
+      return moved;
+    };
     auto rescale_if_needed = [&](float mloc) {
+      if constexpr (EXACT) {
+        float alpha;
+        if (exact_step(mloc, alpha)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) l4[i] *= alpha;
+          o_scale<DT>(alpha);
+        }
+      } else
       if (__any(mloc * sc > mref + 8.f)) {
         const float x = pair_max(mloc) * sc;
         const float nref = fmaxf(mref, x);

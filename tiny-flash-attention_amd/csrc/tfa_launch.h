@@ -25,12 +25,13 @@ struct Variant {
   int rb;   // 32-row query blocks per wave
 };
 
-// ---- the product library: six kernels -------------------------------------------------------------------------------------
+// ---- the product library: seven kernels -------------------------------------------------------------------------------------
 constexpr int kDefaultVariant = 30;       // il8: 256-row blocks, issue-interleaved, 16-bit O through a separate LDS region
 constexpr int kSmallGridVariant = 32;     // il4: 128-row query blocks, two workgroups per CU
 constexpr int kX4D256Variant = 34;        // x4-d256: the only kernel for head dims above 128
 constexpr int kKSplitVariant = 36;        // il8-ksplit: grids of at most one 128-row block per CU
 constexpr int kKSplitPairVariant = 37;    // il8-ksplit-pair: causal grids of at most two 128-row blocks per CU
+constexpr int kExactVariant = 38;         // exact-il8: the il8 kernel with the exact running row maximum — TFA_FWD_EXACT_MAX wherever the default would run il8 (round 5)
 constexpr int kSplitVariant = 17;         // dma4-2buf: the kernel whose grid can carry key chunks (tfa_fwd_splitkv), exact running max (TFA_FWD_EXACT_MAX)
 static const Variant kVariants[] = {
     {17, "dma4-pair-2buf (LDS-DMA, burst-structured, exact running max; 128-row blocks, two LDS buffers: two workgroups per CU)", 4, VF_DMA | VF_PAIR | VF_2BUF, 1},
@@ -43,6 +44,9 @@ static const Variant kVariants[] = {
      VF_DMA | VF_IL | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
     {37, "il8-ksplit-pair-epi (the key-split kernel with causal blocks paired heavy+light per workgroup: two 128-row blocks per CU)", 8,
      VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_EPI_INPLACE | VF_IL_KSPLIT, 1},
+    {38, "exact-il8-pair-dmaspread-epi (variant 30's kernel with the EXACT running row maximum — the reference's rounding points of P, TFA_FWD_EXACT_MAX on grids "
+         "that fill the chip: tiles in which some row of a wave saw a new maximum run a body that also re-bases O behind the QK^T MFMAs)", 8,
+     VF_DMA | VF_IL | VF_PAIR | VF_IL_DMASPREAD | VF_IL_EPI | VF_IL_PREF2 | VF_IL_QLDS | VF_IL_EXACT, 1},
 };
 constexpr int kNumProductVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -87,7 +91,7 @@ static const Variant kExperimentalVariants[] = {
 };
 constexpr int kNumExperimentalVariants = sizeof(kExperimentalVariants) / sizeof(kExperimentalVariants[0]);
 #endif
-constexpr int kNumVariants = 38;          // variant numbers live in [0, kNumVariants); which of them a build carries: variant_info() != nullptr
+constexpr int kNumVariants = 39;          // variant numbers live in [0, kNumVariants); which of them a build carries: variant_info() != nullptr
 
 // the table entry of a variant number, or nullptr when this build does not carry it
 static inline const Variant* variant_info(int variant) {

@@ -17,6 +17,7 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--warm", type=float, default=1.0)
 ap.add_argument("--check", action="store_true", help="also compare every build's output bits with the first build's")
+ap.add_argument("--data", default="normal", choices=["normal", "zeros"], help="normal(0, 0.5) = the reference's recipe (power-capped), zeros = cycle-bound")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 P = C.POINTER(_lib.TfaFwdParams)
@@ -30,7 +31,7 @@ for spec in a.libs:
     entries.append((name, L, int(var) if var else 33))
 for cfg in a.cfgs.split(","):
     B, H, N, D, dt, causal = CFG[cfg]
-    mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(dt)
+    mk = lambda: (torch.zeros((B, H, N, D), dtype=dt, device=dev) if a.data == "zeros" else torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(dt))
     q, k, v = mk(), mk(), mk()
     out = torch.empty_like(q); lse = torch.empty((B, H, N), dtype=torch.float32, device=dev)
     p = ops.make_params(q, k, v, out, lse, causal, 1 / math.sqrt(D))
