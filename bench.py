@@ -58,7 +58,47 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_BF16 = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-MFMA_ONLY_RANDOM_TFLOPS = 1710.0   # measured: a pure v_mfma_f32_32x32x16_bf16 stream on normal(0,0.5) operands, 1.70-1.72 PF at ~1.7 GHz
+
+
+def box_info():
+    """Which box produced this line: host name, the GPU's id and its power cap — boxes of the pool run the same binaries 4-8 % apart on random data
+    (a lower power budget; equally fast on zeros), so a headline is attributable only with these beside it.  Best effort: None where the SMI
+    library does not answer."""
+    info = {"hostname": socket.gethostname(), "gpu_name": None, "gpu_id": None, "power_cap_w": None, "smi": None}
+    try:
+        info["gpu_name"] = torch.cuda.get_device_name(0)
+    except Exception:
+        pass
+    try:
+        import amdsmi
+        amdsmi.amdsmi_init()
+        h = amdsmi.amdsmi_get_processor_handles()[0]
+        info["smi"] = "amdsmi"
+        try:
+            v = amdsmi.amdsmi_get_power_cap_info(h).get("power_cap")
+            info["power_cap_w"] = float(v) / (1e6 if v and v > 100000 else 1.0)
+        except Exception:
+            pass
+        for fn in ("amdsmi_get_gpu_device_uuid", "amdsmi_get_gpu_device_bdf"):
+            try:
+                info["gpu_id"] = str(getattr(amdsmi, fn)(h))
+                break
+            except Exception:
+                continue
+    except Exception:
+        try:
+            r = C.CDLL("/opt/rocm/lib/librocm_smi64.so")
+            if r.rsmi_init(C.c_uint64(0)) == 0:
+                info["smi"] = "rsmi"
+                v = C.c_uint64()
+                if r.rsmi_dev_power_cap_get(0, 0, C.byref(v)) == 0:
+                    info["power_cap_w"] = v.value / 1e6
+                if r.rsmi_dev_unique_id_get(0, C.byref(v)) == 0:
+                    info["gpu_id"] = hex(v.value)
+        except Exception:
+            pass
+    return info
+
 
 CONFIGS = {
     # name: (B, H, N, D, dtype, causal)  — BASELINE.json configs 2..5 (per-GPU shapes)
@@ -213,7 +253,8 @@ def secondary_measurements(dev, budget_s=11.0):
                          "algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
                          "bound": "hbm" if name.startswith("decode") else "mfma",
                          "kernel_variant": _lib.variant_name(L.tfa_fwd_variant(C.byref(p))) if mode in ("fwd", "fwd_exact") else
-                                           (f"tfa_fwd_splitkv, {splits} chunks in one launch + merge" if mode == "split" else "bwd (delta + dQ + dK + dV launches)")}
+                                           (f"tfa_fwd_splitkv, {splits} chunks in one launch + merge" if mode == "split" else
+                                            ("tfa_bwd: dQ launch (forms delta) + fused dK/dV launch" if D <= 128 else "tfa_bwd: dQ (forms delta), dK and dV launches (256-wide kernels)"))}
             del q, k, v, out, lse
         except Exception as e:   # a report, never a reason to lose the headline line
             res[name] = {"error": repr(e)}
@@ -222,7 +263,8 @@ def secondary_measurements(dev, budget_s=11.0):
 
 def workload_text(cfg_name, world, bwd=False, bwd_form="default"):
     B, H, N, D, dtype, causal = CONFIGS[cfg_name]
-    what = ("backward (" + bwd_form + " form: delta + dQ + dK/dV)") if bwd else "forward"
+    what = ("backward (" + bwd_form + " form" + {"default": ": dQ launch, which forms delta, + fused dK/dV launch", "split": ": delta, dQ, dK, dV launches",
+                                                       "workspace": ": delta, fused dK/dV launch keeping dS, dQ from dS"}[bwd_form] + ")") if bwd else "forward"
     shard = (f" = rank's shard of BASELINE config 5 (B=64 over 8 GPUs; here global B={B * world} over {world})" if cfg_name == "cfg5" else "")
     return (f"{cfg_name}: FlashAttention-2 {what}, per-GPU B={B} H={H} N={N} D={D} {'causal' if causal else 'full'}{shard}, "
             f"q/k/v normal(0,0.5) resident in HBM, scale=1/sqrt(D)")
@@ -315,8 +357,8 @@ def fake_run(args, world, rank, cfg_name, do_gather):
         fn = lambda a, b_, c, cz, s_, o: (time.sleep(args.fake_step_ms * 1e-3 * a.shape[0] / B), o.fill_(float(rank + 1)))[1]
         gth = tdist.OverlappedGather(q, q, q, causal, sc, world, rank, chunks=args.gather_chunks, fn=fn)
         wall_g = region(gth.step, gth.join)
-        full = gth.result()
-        ok = all(bool((full[r * B:(r + 1) * B] == float(r + 1)).all()) for r in range(world))
+        res = gth.result()                          # zero-copy view over the per-chunk gather buffers
+        ok = len(res) == world * B and all(bool((t == float(row // B + 1)).all()) for row, t in res)
         line["gather"] = {"value": total / wall_g / 1e12, "unit": "TFLOP/s", "ms_per_step": wall_g / args.steps * 1e3, "chunks": gth.nchunks,
                           "gathered_rows_ok": ok}
     if dist.is_initialized():
@@ -554,6 +596,16 @@ def main():
             step()
         clk_mhz = shader_clock_mhz()
 
+    # ---- 6a. what nothing but MFMAs sustains on this box, on this q tensor's values (1.5 s, rank 0, one GPU): quoted beside the nominal peak
+    mfma_ceiling = None
+    if rank == 0 and world == 1 and not bwd and dtype == torch.bfloat16:
+        try:
+            tf_ = C.c_double()
+            _lib.check(L.tfa_debug_mfma_ceiling(C.c_void_p(q.data_ptr()), C.c_ulonglong(q.numel() * q.element_size()), C.c_double(1.5), sptr, C.byref(tf_)))
+            mfma_ceiling = tf_.value
+        except Exception:
+            mfma_ceiling = None
+
     fl, by = C.c_double(), C.c_double()
     if bwd:
         L.tfa_bwd_work(pbref, C.byref(fl), C.byref(by))
@@ -607,6 +659,7 @@ def main():
                 "flops_per_step_per_gpu": flops_step_rank,
                 "algorithmic_bytes_per_step_per_gpu": by.value,
             },
+            "box": box_info(),
             "preconditioning": precond,
             "per_launch_ms": per_launch,
             "per_launch_tflops": {"median": tf(per_launch["median"]), "best": tf(per_launch["min"])},
@@ -625,10 +678,11 @@ def main():
                 "sustained_clock_mhz": clk_mhz,
                 "peak_at_sustained_clock": (PEAK_TFLOPS_BF16 * clk_mhz / 2400.0) if clk_mhz else None,
                 "frac_at_sustained_clock": (achieved / (PEAK_TFLOPS_BF16 * clk_mhz / 2400.0)) if clk_mhz else None,
-                # what nothing-but-MFMA sustains on normal(0,0.5) operands under this board's 1400 W cap (tools/probe_mfma_power.hip,
-                # profiles/r03_mfma_power_ceiling.txt): reported beside the nominal peak, never instead of it
-                "mfma_only_ceiling_random_data": MFMA_ONLY_RANDOM_TFLOPS,
-                "frac_of_mfma_only_ceiling": achieved / MFMA_ONLY_RANDOM_TFLOPS,
+                # what nothing-but-MFMA sustains on THIS box on this q tensor's normal(0,0.5) values under the board's power cap — measured in this
+                # run (tfa_debug_mfma_ceiling, 1.5 s behind the timed regions; boxes differ by +-5 %): beside the nominal peak, never instead of it
+                "mfma_only_ceiling_random_data": mfma_ceiling,
+                "mfma_only_ceiling_source": "measured in this run: tfa_debug_mfma_ceiling on the q tensor (csrc/tfa_probe.hip)" if mfma_ceiling else None,
+                "frac_of_mfma_only_ceiling": (achieved / mfma_ceiling) if mfma_ceiling else None,
                 "algorithmic_hbm_GBs": by.value / (ev_ms * 1e-3) / 1e9,
                 "hbm_frac": by.value / (ev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },

@@ -532,3 +532,38 @@ def test_work_item_decode_matches_plain_divisions():
         assert L.tfa_debug_decode(B, H, Hk, nwork, id, out) == 0
         assert tuple(out) == plain(id, B, H, Hk, nwork)
     assert n > 10000
+
+
+def test_outputs_that_alias_themselves_and_fp32_split_are_refused():
+    """an `out` whose (b,h) slices share memory (broadcast batch / head stride, interleaved slices) would be written by several
+    workgroups at once — TFA_ERR_STRIDE on the 16-bit and the fp32 path alike, while INPUTS may broadcast; fp32 q, k, v are tfa_fwd only:
+    tfa_fwd_splitkv / its workspace query answer TFA_ERR_DTYPE on either of their routes."""
+    L = _lib.lib()
+    for dt in (_lib.TFA_BF16, _lib.TFA_F32):
+        mk = lambda: _params(B=2, H=4, Hk=4, Nq=128, Nk=128, dtype=dt, out_dtype=_lib.TFA_F32 if dt == _lib.TFA_F32 else None)
+        assert plan(mk())[0] == 0
+        p = mk(); p.o_stride[1] = 0
+        assert plan(p)[0] == -5, "out broadcast over heads"
+        p = mk(); p.o_stride[0] = 0
+        assert plan(p)[0] == -5, "out broadcast over the batch"
+        p = mk(); p.o_stride[1] = 64 * 128                              # head slices overlap by half
+        assert plan(p)[0] == -5
+        p = mk(); p.q_stride[1] = 0; p.k_stride[0] = 0                  # inputs may broadcast
+        assert plan(p)[0] == 0
+        p = mk()                                                         # (B,N,H,D) output: heads interleaved inside a row — legal
+        p.o_stride[0], p.o_stride[1], p.o_stride[2] = 128 * 4 * 128, 128, 4 * 128
+        assert plan(p)[0] == 0
+    f = _params(B=1, H=2, Hk=2, Nq=1, Nk=8192, dtype=_lib.TFA_F32, out_dtype=_lib.TFA_F32)
+    L.tfa_fwd_splitkv_workspace.restype = C.c_longlong
+    assert L.tfa_fwd_splitkv_workspace(C.byref(f), 4) == -2            # TFA_ERR_DTYPE
+    assert L.tfa_fwd_splitkv(C.byref(f), 4, C.c_void_p(0x1000), None) == -2
+
+
+def test_fp32_tensors_name_the_fix_on_the_16_bit_only_entries():
+    """make_params / make_bwd_params raised a bare KeyError(torch.float32)."""
+    import torch
+    from tiny_flash_attention_amd import ops
+    t = torch.zeros((1, 1, 8, 8), dtype=torch.float32)
+    l = torch.zeros((1, 1, 8), dtype=torch.float32)
+    with pytest.raises(TypeError, match="float16 or bfloat16 only"):
+        ops.make_bwd_params(t, t, t, t, l, t, t, t, t, l, False, 1.0)

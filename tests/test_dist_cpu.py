@@ -150,9 +150,16 @@ def _og_worker(rank, world, port, shape, causal, chunks, q_out):
     og.step()                                                      # a second step re-uses the slabs
     og.join()
     ok = og.nchunks == min(chunks, Bl)
+    res = og.result()                                              # zero-copy view over the chunk buffers the collectives wrote
+    ok = ok and len(res) == world * Bl
     for r in range(world):                                         # every rank's slab, recomputed locally from its seed
         qr, kr, vr = O.make_inputs(Bl, H, N, D, torch.float32, seed=100 + r)
-        ok = ok and bool(torch.equal(og.full[r * Bl:(r + 1) * Bl], O.flash_attn(qr, kr, vr, causal, sc)))
+        want = O.flash_attn(qr, kr, vr, causal, sc)
+        ok = ok and bool(torch.equal(og.full[r * Bl:(r + 1) * Bl], want))              # the assembled copy ...
+        for lo, hi, view in res.slab(r):                                               # ... and the views: same values, and they ARE the gather buffers
+            ok = ok and bool(torch.equal(view, want[lo:hi])) and any(view.data_ptr() == og.parts[c][r].data_ptr() for c in range(og.nchunks))
+        ok = ok and all(bool(torch.equal(res.batch(r, b), want[b])) for b in range(Bl))
+    ok = ok and [row for row, _ in res] == list(range(world * Bl))
     q_out.put((rank, ok, "og"))
     dist.barrier()
     dist.destroy_process_group()

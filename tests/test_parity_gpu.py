@@ -1051,6 +1051,27 @@ def test_hip_graph_capture_and_replay(tfa, oracle, dev):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype,D,N", [
+    (torch.bfloat16, 96, 777),      # narrow instantiation (last 32-column block empty), ragged last query block, two causal pairs
+    (torch.bfloat16, 120, 1000),    # main instantiation with its last 16-byte chunk masked (dv < D), ragged
+    (torch.bfloat16, 128, 513),     # main, one row in the last block: the light pass of pair (2, 0) follows a nearly empty heavy pass
+    (torch.float16, 32, 700),       # 64-wide narrow
+    (torch.float16, 56, 1030),      # 64-wide main, masked chunk
+])
+def test_light_pass_prefetch_under_masked_chunks_and_ragged_rows(tfa, oracle, dev, dtype, D, N):
+    """The paired causal il8 kernel (variant 30) requests its light pass's Q rows and first tiles in FRONT of the heavy pass's O stores and waits for
+    them with a counted `vmcnt(NST_EPI)` behind them (VF_IL_PREF2): that is correct only while every store instruction is issued, also for
+    16-byte chunks beyond the head dim and rows beyond Nq (they go out of range, they are not skipped; tfa_fwd_il_epilogue.inc pins the count with
+    static_asserts).  Shapes that exercise exactly those stores, 16-bit and fp32 output, against the oracle."""
+    from tiny_flash_attention_amd import _lib
+
+    _lib.set_variant(30)
+    try:
+        run_case(tfa, oracle, dev, dtype, 2, 3, N, D, True, seed=77 + D)
+    finally:
+        _lib.set_variant(-1)
+
+
 @pytest.mark.parametrize("variant", _avail([30, 32]))
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 96), (torch.bfloat16, 72), (torch.float16, 32), (torch.float16, 24)])

@@ -11,6 +11,7 @@ TFA_F16, TFA_BF16, TFA_F32 = 0, 1, 2
 # every symbol include/tfa.h declares
 SYMBOLS = (
     "tfa_version",
+    "tfa_debug_mfma_ceiling",
     "tfa_strerror",
     "tfa_fwd",
     "tfa_fwd_bhnd",
@@ -159,6 +160,8 @@ def lib():
     L.tfa_debug_set_flags.argtypes = [C.c_int]
     L.tfa_debug_set_trace.restype = C.c_int
     L.tfa_debug_set_trace.argtypes = [C.c_void_p]
+    L.tfa_debug_mfma_ceiling.restype = C.c_int
+    L.tfa_debug_mfma_ceiling.argtypes = [C.c_void_p, C.c_ulonglong, C.c_double, C.c_void_p, C.POINTER(C.c_double)]
     L.tfa_fwd_splitkv.restype = C.c_int
     L.tfa_fwd_splitkv.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p]
     L.tfa_fwd_suggest_splits.restype = C.c_int

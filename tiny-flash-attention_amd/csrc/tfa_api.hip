@@ -35,6 +35,25 @@ bool one_descriptor(const tfa_fwd_params* p) {
   return small(p->Nq, p->q_stride, 2) && small(p->Nk, p->k_stride, 2) && small(p->Nk, p->v_stride, 2) && small(p->Nq, p->o_stride, 4);
 }
 
+// An OUTPUT whose (b,h) slices share memory — a broadcast batch or head stride, or slices that interleave — would be written by several
+// workgroups at once (inputs may broadcast freely: they are only read).  Row overlap inside a slice is the callers' `stride[2] < D` test.
+bool out_aliases_itself(const tfa_fwd_params* p) {
+  // the dims that have more than one index, by ascending stride: each stride must clear the span of everything below it (rows of D elements
+  // at the bottom).  Sufficient, and every layout a tensor library hands out — (B,H,N,D), (B,N,H,D), slices and views of them — passes
+  int64_t st[3] = {p->o_stride[0], p->o_stride[1], p->o_stride[2]};
+  int64_t ext[3] = {p->B, p->H, p->Nq};
+  for (int i = 0; i < 3; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (st[j] < st[i]) { const int64_t t = st[i]; st[i] = st[j]; st[j] = t; const int64_t e = ext[i]; ext[i] = ext[j]; ext[j] = e; }
+  int64_t span = p->D;
+  for (int i = 0; i < 3; ++i) {
+    if (ext[i] <= 1) continue;
+    if (st[i] < span) return true;
+    span = (ext[i] - 1) * st[i] + span;
+  }
+  return false;
+}
+
 // NOTE on tfa_set_variant (a per-thread debug knob): a forced variant means "run exactly that kernel on the problem as given" —
 // GQA row packing (pack_gqa_rows) and tfa_fwd_suggest_splits are both switched off while one is set, and head dims above 128
 // always run kX4D256Variant (the only kernel that wide).  Tools that force a variant reset it to -1 in a finally block.
@@ -125,6 +144,7 @@ int validate(const tfa_fwd_params* p, tfa::KArgs* a, int variant, int row_mod = 
     }
     if (st[t][2] < p->D) return TFA_ERR_STRIDE;               // rows must not overlap
   }
+  if (out_aliases_itself(p)) return TFA_ERR_STRIDE;
   if (((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->out) & 15) return TFA_ERR_ALIGN;
   if (p->lse && ((uintptr_t)p->lse & 3)) return TFA_ERR_ALIGN;
 
@@ -219,6 +239,8 @@ int run_f32(const tfa_fwd_params* p, void* stream, tfa::LaunchGeom* geom, bool d
       if (st[t][i] < 0 || (st[t][i] * 4) % 16 != 0) return TFA_ERR_STRIDE;
     if (st[t][2] < p->D) return TFA_ERR_STRIDE;
   }
+  if (out_aliases_itself(p)) return TFA_ERR_STRIDE;
+  if (p->Nq >= 0x3fffffff) return TFA_ERR_SHAPE;                          // (the kernel forms row + 32 + shift in 32-bit arithmetic)
   if (((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->out) & 15) return TFA_ERR_ALIGN;
   if (p->lse && ((uintptr_t)p->lse & 3)) return TFA_ERR_ALIGN;
   tfa::KArgs a;
@@ -383,6 +405,7 @@ SideStreams* side_streams() {
 // ---- split-KV in one launch ------------------------------------------------------------------------------------------
 static int splitkv_geometry(const tfa_fwd_params* p, int splits, int* nsplit, int* chunk) {
   if (!p || splits < 1) return TFA_ERR_SHAPE;
+  if (p->dtype == TFA_F32) return TFA_ERR_DTYPE;                             // fp32 q, k, v: tfa_fwd only (tfa.h) — whichever route the call would take
   if (p->kv_offset != 0 || p->nk_total != 0) return TFA_ERR_SHAPE;          // the call splits the WHOLE key sequence
   int c = (p->Nk + splits - 1) / splits;
   c = (c + 63) / 64 * 64;
@@ -462,7 +485,6 @@ int tfa_fwd_splitkv(const tfa_fwd_params* p, int splits, float* workspace, void*
     }
     if (st_chunks != TFA_OK) return st_chunks;
     if (st_join != TFA_OK) return st_join;                 // (HIP errors are reported as positive status codes: tfa_strerror)
-    if (st_chunks != TFA_OK) return st_chunks;
     return tfa_merge(ws_o, ws_l, ns, rows, p->D, rows * p->D, rows, p->out, p->out_dtype, p->lse, stream);
   }
   const int variant = tfa::kSplitVariant;                 // the LDS-DMA kernel carries the chunk dimension in its grid

@@ -166,8 +166,9 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry, long long* ws_need 
   const bool use_ws = p->workspace != nullptr && ws_form && ws_avail >= need;
   // delta = rowsum(dout o out): the dQ launch computes it from its resident dO rows and the O rows and writes it for the launches behind it
   // (BArgs::fuse_delta; 51 us and one pass over dO less at config 3) — unless the fused dK/dV launch runs FIRST (the workspace form), or
-  // tfa_debug_bwd_split bit 8 asks for the launch of its own (A/B, tests)
+  // tfa_debug_bwd_split value 8 (bit 3) asks for the launch of its own (A/B, tests)
   const bool fuse_delta = !use_ws && !(g_bwd_split & 8);
+  // (always: the dQ launch reads O only when it forms delta, but fill() is also what validates out's strides and slice size for every form)
   if (!fill(&a.out, p->out, p->o_stride, p->Nq, p->D, esz, bigp)) return TFA_ERR_STRIDE;
   a.delta_w = p->delta;
   a.fuse_delta = fuse_delta ? 1 : 0;

@@ -103,10 +103,11 @@ __global__ __launch_bounds__(256) void fwd_kernel_f32(const KArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kv = k0 + 8 * (r >> 2) + 4 * hi + (r & 3);            // the key whose P this lane holds in ps[r]
-      const float* vrow = vb + (long long)(kv < p.Nk ? kv : p.Nk - 1) * p.vs_n;
+      const bool kv_ok = kv < p.Nk;                                      // (a padded key contributes 0, not 0 * V[Nk-1]: no Inf / NaN leaks out of the clamped row)
+      const float* vrow = vb + (long long)(kv_ok ? kv : p.Nk - 1) * p.vs_n;
 #pragma unroll
       for (int d = 0; d < DM / 32; ++d) {
-        const float a = (d * 32 + qi < p.dv) ? vrow[d * 32 + qi] : 0.f;
+        const float a = (kv_ok && d * 32 + qi < p.dv) ? vrow[d * 32 + qi] : 0.f;
         O[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ps[r], O[d], 0, 0, 0);
       }
     }

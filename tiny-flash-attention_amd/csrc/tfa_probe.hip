@@ -1,0 +1,69 @@
+// tfa_probe.hip — tfa_debug_mfma_ceiling: what nothing but v_mfma_f32_32x32x16_bf16 sustains on THIS box, on the caller's operand values.
+// The forward kernel runs at the board's power cap on the reference's normal(0, 0.5) inputs, so the nominal 2.5 PF (a 2.4 GHz figure) is not
+// reachable on that data by any instruction stream; the sustained rate of a bare MFMA stream varies by +-5 % between boxes of the pool
+// (docs/LABLOG.md L-6: 1.69-1.85 PF).  bench.py measures it in the same run, on the same q tensor, and quotes it BESIDE the nominal peak
+// (`roofline.mfma_only_ceiling_random_data`) — never instead of it.  Same stream as tools/probe_mfma_power.hip: two waves per SIMD, operands
+// in registers, a new A fragment every MFMA, a new B fragment every second MFMA, four accumulators round-robin (how the attention loop rotates them).
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include "tfa.h"
+
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__global__ __launch_bounds__(512, 2) void mfma_stream(const u32x4* src, unsigned chunk_mask, float* sink, int iters) {
+  const unsigned tid = blockIdx.x * 512 + threadIdx.x;
+  bf16x8 a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = __builtin_bit_cast(bf16x8, src[(tid * 16 + i) & chunk_mask]);
+    b[i] = __builtin_bit_cast(bf16x8, src[(tid * 16 + 8 + i) & chunk_mask]);
+  }
+  f32x16 c[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[k][r] = 0.f;
+#pragma nounroll
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 32; ++m) c[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m & 7], b[(m / 2) & 7], c[m & 3], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += c[k][r];
+  if (s == 123.456f && sink) sink[tid] = s;      // (never true for finite data: keeps the accumulators alive)
+}
+}  // namespace
+
+extern "C" int tfa_debug_mfma_ceiling(const void* operands, unsigned long long bytes, double seconds, void* stream, double* tflops) {
+  if (!operands || !tflops || bytes < (1ull << 16) || !(seconds > 0.0) || seconds > 30.0) return TFA_ERR_NULL;
+  unsigned chunks = 1;                             // largest power of two of 16-byte chunks inside the buffer
+  while ((unsigned long long)chunks * 2 * 16 <= bytes && chunks < (1u << 24)) chunks *= 2;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipGetLastError();
+  const int grid = 1024, iters = 2000, reps = 4;
+  const double flops = (double)grid * 8 * iters * 32 * 32768.0 * reps;
+  double last = 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = TFA_OK;
+  do {                                             // the last group's rate: the clock has settled on this stream by then
+    (void)hipGetLastError();
+    hipEventRecord(e0, s);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mfma_stream, dim3(grid), dim3(512), 0, s, (const u32x4*)operands, chunks - 1, (float*)nullptr, iters);
+    hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) { rc = (int)hipGetLastError(); break; }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms > 0.f) last = flops / (ms * 1e-3) / 1e12;
+  } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (rc == TFA_OK) *tflops = last;
+  return rc;
+}

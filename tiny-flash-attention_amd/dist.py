@@ -131,6 +131,38 @@ def kv_sharded_forward(q, k_local, v_local, is_causal, softmax_scale, kv_offset,
     return merge_fn(o_all, l_all, out_dtype)
 
 
+class Gathered:
+    """Zero-copy view of an OverlappedGather's output: rank r's batch b is global row r*B + b; chunk c holds the batch rows bounds[c] of every rank."""
+
+    def __init__(self, parts, bounds, world, B):
+        self.parts, self.bounds, self.world, self.B = parts, bounds, world, B
+
+    def slab(self, r):
+        """rank r's (B, H, N, D) output as a list of (lo, hi, view) — one view per chunk, no copy"""
+        return [(lo, hi, self.parts[c][r]) for c, (lo, hi) in enumerate(self.bounds)]
+
+    def batch(self, r, b):
+        """rank r's batch element b: an (H, N, D) view"""
+        for c, (lo, hi) in enumerate(self.bounds):
+            if lo <= b < hi:
+                return self.parts[c][r, b - lo]
+        raise IndexError(b)
+
+    def __len__(self):
+        return self.world * self.B
+
+    def __iter__(self):
+        """(global row, (H, N, D) view) in global row order"""
+        for r in range(self.world):
+            for b in range(self.B):
+                yield r * self.B + b, self.batch(r, b)
+
+    def cat(self):
+        """the assembled (world*B, H, N, D) tensor — a COPY when there is more than one chunk"""
+        full = self.parts[0] if len(self.parts) == 1 else torch.cat(self.parts, dim=1)
+        return full.reshape((self.world * self.B,) + tuple(full.shape[2:]))
+
+
 class OverlappedGather:
     """Forward over this rank's batch slab + the "trivial gather" of all ranks' outputs, with the gather hidden behind
     the compute ("overlap the gather with compute by chunking over B").
@@ -139,9 +171,9 @@ class OverlappedGather:
     queues chunk c's all-gather on a side stream behind an event, so that RCCL moves chunk c over xGMI while chunk c+1
     computes; only the last chunk's gather is exposed.  (b,h) problems are independent
     (flash_attention_cutlass/csrc/flash_attention.cu:382,409,698), so chunking changes no result bit.  Each chunk is gathered
-    with ONE all_gather_into_tensor into its own contiguous buffer `parts[c]` (world, rows, H, N, D); `result()` (alias
-    `full`) joins and returns the whole (world*B, H, N, D) output, rank r's batch b at row r*B + b; `join()` makes the
-    current stream wait for the outstanding gathers.
+    with ONE all_gather_into_tensor into its own contiguous buffer `parts[c]` (world, rows, H, N, D); `result()` joins and returns
+    a zero-copy `Gathered` view of those buffers (rank r's batch b = global row r*B + b; `.cat()` / the `full` property assemble
+    one tensor — a copy); `join()` makes the current stream wait for the outstanding gathers.
     `fn(q,k,v,is_causal,scale,out) -> None` defaults to the HIP operator writing into `out`; `device='cpu'` tensors
     (the gloo tests) run the same schedule without streams."""
 
@@ -176,16 +208,16 @@ class OverlappedGather:
         dist.all_gather_into_tensor(self.parts[c].view(-1), self.out[lo:hi].reshape(-1), group=self.group)
 
     def result(self):
-        """The gathered output of all ranks, (world*B, H, N, D) with rank r's batch b at row r*B + b, after join().
-        (Assembled from the per-chunk buffers: a copy when there is more than one chunk — consumers that can work chunk by
-        chunk read `parts[c]`, shape (world, rows of chunk c, H, N, D), directly.)"""
+        """The gathered output of all ranks after join(), WITHOUT copying it: a `Gathered` view over the per-chunk buffers the collectives wrote
+        (`parts[c]`, shape (world, rows of chunk c, H, N, D)).  `res.slab(r)` / `res.batch(r, b)` / iteration hand out views; `res.cat()` — and
+        the `full` property — assemble the (world*B, H, N, D) tensor, which is a copy of the whole output (2.1 GB per call at BASELINE config 5 on
+        8 ranks) and is there for callers that really need one contiguous tensor."""
         self.join()
-        full = self.parts[0] if self.nchunks == 1 else torch.cat(self.parts, dim=1)
-        return full.reshape((self.world * self.q.shape[0],) + tuple(self.q.shape[1:]))
+        return Gathered(self.parts, self.bounds, self.world, self.q.shape[0])
 
     @property
     def full(self):
-        return self.result()
+        return self.result().cat()
 
     def step(self):
         if not self.cuda:

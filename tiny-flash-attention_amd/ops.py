@@ -16,6 +16,15 @@ _DT_IN = dict(_DT)
 _DT_IN[torch.float32] = _lib.TFA_F32    # fp32 q,k,v: the fp32 correctness path (the reference's fp32 fixtures; tfa_fwd_f32.hip) — forward only
 
 
+def _dt16(t, what):
+    """dtype code of a float16 / bfloat16 tensor for the entries that have no fp32 path (backward, split-KV, raw parameter blocks)."""
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"{what}: float16 or bfloat16 only (got {t.dtype}); the fp32 path is forward-only — ops.flash_attn_fwd / tfa_fwd "
+                        "with dtype = TFA_F32") from None
+
+
 def _check_input(x, name):
     # CHECK_INPUT of the reference (flash_attention_cutlass/include/attention_api.cuh:12-18)
     if not x.is_cuda:
@@ -186,8 +195,8 @@ def make_params(q, k, v, out, lse, is_causal, softmax_scale, layout="bhnd"):
         arr[0], arr[1], arr[2] = s
     p.softmax_scale = float(softmax_scale)
     p.is_causal = 1 if is_causal else 0
-    p.dtype = _DT[q.dtype]
-    p.out_dtype = _lib.TFA_F32 if out.dtype == torch.float32 else _DT[out.dtype]
+    p.dtype = _dt16(q, "make_params (q, k, v)")
+    p.out_dtype = _lib.TFA_F32 if out.dtype == torch.float32 else _dt16(out, "make_params (out)")
     return p
 
 
@@ -211,8 +220,8 @@ def make_bwd_params(q, k, v, out, lse, dout, dq, dk, dv, delta, is_causal, softm
         arr[0], arr[1], arr[2] = s
     p.softmax_scale = float(softmax_scale)
     p.is_causal = 1 if is_causal else 0
-    p.dtype = _DT[q.dtype]
-    p.grad_dtype = _lib.TFA_F32 if dq.dtype == torch.float32 else _DT[dq.dtype]
+    p.dtype = _dt16(q, "backward (q, k, v)")
+    p.grad_dtype = _lib.TFA_F32 if dq.dtype == torch.float32 else _dt16(dq, "backward (gradients)")
     return p
 
 
