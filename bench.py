@@ -596,12 +596,12 @@ def main():
             step()
         clk_mhz = shader_clock_mhz()
 
-    # ---- 6a. what nothing but MFMAs sustains on this box, on this q tensor's values (1.5 s, rank 0, one GPU): quoted beside the nominal peak
+    # ---- 6a. what nothing but MFMAs sustains on this box, on this q tensor's values (2 s, rank 0, one GPU): quoted beside the nominal peak
     mfma_ceiling = None
     if rank == 0 and world == 1 and not bwd and dtype == torch.bfloat16:
         try:
             tf_ = C.c_double()
-            _lib.check(L.tfa_debug_mfma_ceiling(C.c_void_p(q.data_ptr()), C.c_ulonglong(q.numel() * q.element_size()), C.c_double(1.5), sptr, C.byref(tf_)))
+            _lib.check(L.tfa_debug_mfma_ceiling(C.c_void_p(q.data_ptr()), C.c_ulonglong(q.numel() * q.element_size()), C.c_double(2.0), sptr, C.byref(tf_)))
             mfma_ceiling = tf_.value
         except Exception:
             mfma_ceiling = None
@@ -679,7 +679,7 @@ def main():
                 "peak_at_sustained_clock": (PEAK_TFLOPS_BF16 * clk_mhz / 2400.0) if clk_mhz else None,
                 "frac_at_sustained_clock": (achieved / (PEAK_TFLOPS_BF16 * clk_mhz / 2400.0)) if clk_mhz else None,
                 # what nothing-but-MFMA sustains on THIS box on this q tensor's normal(0,0.5) values under the board's power cap — measured in this
-                # run (tfa_debug_mfma_ceiling, 1.5 s behind the timed regions; boxes differ by +-5 %): beside the nominal peak, never instead of it
+                # run (tfa_debug_mfma_ceiling: median of 2 s of launches behind the timed regions; boxes differ by +-5 %): beside the nominal peak, never instead of it
                 "mfma_only_ceiling_random_data": mfma_ceiling,
                 "mfma_only_ceiling_source": "measured in this run: tfa_debug_mfma_ceiling on the q tensor (csrc/tfa_probe.hip)" if mfma_ceiling else None,
                 "frac_of_mfma_only_ceiling": (achieved / mfma_ceiling) if mfma_ceiling else None,

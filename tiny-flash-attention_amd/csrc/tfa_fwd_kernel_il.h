@@ -69,6 +69,10 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
 
 }  // namespace tfa
 #include "tfa_fwd_il_regs.h"
+#include "tfa_fwd_il_asm_loop.inc"
+#if !defined(TFA_IL_USE_ASMLOOP)
+#define TFA_IL_USE_ASMLOOP 1     // 0: the compiler-scheduled body everywhere (the A/B arm of the hand-scheduled steady state, tools/r5_arm.sh)
+#endif
 
 // Timing probe (never in the product build): -DTFA_IL_PAD=n -DTFA_IL_PADKIND=k puts n extra do-nothing instructions behind every MFMA of the
 // fast path — k = 0 s_nop 0, 1 SALU (s_mov_b32 to a dead register), 2 VALU (v_mov_b32 to a dead register), 3 s_waitcnt with counts nothing reaches.
@@ -310,12 +314,18 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     const int ntx = own_tiles(kve > 0 ? (kve + BN - 1) / BN : 0);
     if (with_dma && ntx > 0) dma_k(0, 0);
     if (with_dma && ntx > 0) dma_v(0, 0);
-    if (with_dma && ntx > 1) dma_k(1, 1);
+    int one = 1;                                       // (opaque: K(1)'s source offsets are otherwise shared with the first prologue's and live across the tile loop)
+    asm volatile("" : "+s"(one));
+    if (with_dma && ntx > 1) dma_k(one, 1);
     auto q_rs = slice_rsrc(qbase, p.q_bytes, (unsigned long long)q0x * (unsigned long long)p.qs_n * 2ull);
-    const int qoff = ((WIN ? 0 : q0x) + wrow * 32 + qi) * (int)p.qs_n * 2 + hi * 16;
+    // (the half-wave index goes through an empty asm: otherwise hipcc hoists the eight per-k-slot offsets out of the pass loop, where they stay live
+    //  across the tile loop — eight registers the loop does not have, round 5)
+    int hix = hi;
+    asm volatile("" : "+v"(hix));
+    const int qoff = ((WIN ? 0 : q0x) + wrow * 32 + qi) * (int)p.qs_n * 2 + hix * 16;
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
-      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, (2 * s + hi) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB, 0, 0);
+      u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, (2 * s + hix) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB, 0, 0);
       qf[s] = __builtin_bit_cast(X8, t);
     }
   };

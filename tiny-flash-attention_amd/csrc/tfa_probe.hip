@@ -6,6 +6,7 @@
 // in registers, a new A fragment every MFMA, a new B fragment every second MFMA, four accumulators round-robin (how the attention loop rotates them).
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <algorithm>
 #include "tfa.h"
 
 namespace {
@@ -47,12 +48,13 @@ extern "C" int tfa_debug_mfma_ceiling(const void* operands, unsigned long long b
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipGetLastError();
-  const int grid = 1024, iters = 2000, reps = 4;
+  const int grid = 1024, iters = 4000, reps = 2;   // ~40 ms per group: host round trips between groups stay below 0.3 %
   const double flops = (double)grid * 8 * iters * 32 * 32768.0 * reps;
-  double last = 0.0;
+  double rates[512];
+  int nr = 0;
   const auto t0 = std::chrono::steady_clock::now();
   int rc = TFA_OK;
-  do {                                             // the last group's rate: the clock has settled on this stream by then
+  do {                                             // groups of `reps` launches between two events; the median of the second half of the groups is reported
     (void)hipGetLastError();
     hipEventRecord(e0, s);
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mfma_stream, dim3(grid), dim3(512), 0, s, (const u32x4*)operands, chunks - 1, (float*)nullptr, iters);
@@ -60,10 +62,19 @@ extern "C" int tfa_debug_mfma_ceiling(const void* operands, unsigned long long b
     if (hipEventSynchronize(e1) != hipSuccess) { rc = (int)hipGetLastError(); break; }
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
-    if (ms > 0.f) last = flops / (ms * 1e-3) / 1e12;
+    if (ms > 0.f && nr < 512) rates[nr++] = flops / (ms * 1e-3) / 1e12;
   } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds);
   hipEventDestroy(e0);
   hipEventDestroy(e1);
-  if (rc == TFA_OK) *tflops = last;
+  if (rc == TFA_OK && nr > 0) {                    // (the first half of the groups is the clock settling on this stream: the firmware's power loop swings +-15 % per group)
+    const int lo = nr / 2, n = nr - lo;
+    for (int i = lo + 1; i < nr; ++i) {            // insertion sort of the second half
+      const double x = rates[i];
+      int j = i - 1;
+      while (j >= lo && rates[j] > x) { rates[j + 1] = rates[j]; --j; }
+      rates[j + 1] = x;
+    }
+    *tflops = rates[lo + n / 2];
+  }
   return rc;
 }

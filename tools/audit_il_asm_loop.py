@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Static audit of the hand-scheduled tile loop (tfa_fwd_il_asm_loop.inc) on the DISASSEMBLED object — registers resolved, unlike the .s file, whose asm
+text still carries the assembler symbols.  usage: audit_il_asm_loop.py file.o [kernel-name substring]   (exit status 1 on any finding)
+
+Finds the loop (from its label-less head: the first ds_read_b128 behind the seven v_xor_b32 that build the K fragment addresses, to the backward
+s_branch) in every kernel that has one and checks, per tile body:
+  1. every LDS-read destination is complete (s_waitcnt lgkmcnt, LDS returns in order) before an instruction reads it;
+  2. a VALU write of an MFMA A/B/C operand is >= 2 instructions in front of the MFMA;
+  3. an MFMA result is >= 12 instructions old when a non-MFMA instruction reads or overwrites it (8-pass MFMA);
+  4. an LDS read never lands in a fragment buffer whose MFMA was issued fewer than 1 MFMA ago (the distance hipcc's own schedule keeps);
+  5. the block is ONE basic block per tile (no branch targets inside), and reports its instruction mix."""
+import collections
+import re
+import subprocess
+import sys
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def regs(tok):
+    tok = tok.strip()
+    neg = tok.startswith("-")
+    if neg:
+        tok = tok[1:]
+    m = re.match(r"^v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return list(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"^v(\d+)$", tok)
+    return [int(m.group(1))] if m else []
+
+
+def parse(line):
+    t = line.split("//")[0].strip()
+    if not t:
+        return None
+    parts = t.split(None, 1)
+    op = parts[0]
+    ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+    ops = [o.split(" offset:")[0].split(" op_sel")[0] for o in ops]
+    return op, ops
+
+
+def main():
+    obj = sys.argv[1]
+    pat = sys.argv[2] if len(sys.argv) > 2 else "fwd_kernel_il"
+    txt = subprocess.run([OBJDUMP, "-d", obj], stdout=subprocess.PIPE, text=True).stdout
+    kernels, cur = collections.OrderedDict(), None
+    for line in txt.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            if m.group(1).startswith("_Z") or cur is None:      # (local labels of an asm statement — il_loop0, il_exit0 — belong to the kernel around them)
+                cur = m.group(1)
+                kernels[cur] = []
+            continue
+        if cur is not None and line.startswith("\t"):
+            p = parse(line)
+            if p:
+                kernels[cur].append(p)
+    bad, found = 0, 0
+    for name, ins in kernels.items():
+        if pat not in name:
+            continue
+        # the loop: seven consecutive v_xor_b32 (K addresses), a v_add_f32 (thr), then bodies up to the backward s_branch
+        start = None
+        for i in range(len(ins) - 8):
+            if all(ins[i + k][0].startswith("v_xor_b32") for k in range(7)) and ins[i + 7][0].startswith("v_add_f32"):
+                start = i + 8
+                break
+        if start is None:
+            continue
+        end = next(i for i in range(start, len(ins)) if ins[i][0] == "s_branch")
+        loop = ins[start:end]
+        found += 1
+        n_tiles = sum(1 for op, _ in loop if op == "s_barrier")
+        mix = collections.Counter()
+        for op, _ in loop:
+            k = ("mfma" if op.startswith("v_mfma") else "trans" if op.startswith("v_exp") else "valu" if op.startswith("v_") else "lds" if op.startswith("ds_")
+                 else "vmem" if op.startswith("buffer_") else "waitcnt" if op == "s_waitcnt" else "barrier" if op == "s_barrier" else "branch" if "branch" in op else "salu")
+            mix[k] += 1
+        print(f"{name[:100]}\n   loop: {len(loop)} instructions, {n_tiles} tiles -> {len(loop) / n_tiles:.0f} per tile: " +
+              "  ".join(f"{k} {v / n_tiles:.1f}" for k, v in sorted(mix.items())))
+        pending = collections.deque()          # LDS reads in flight: destination registers, in issue order
+        inflight = set()
+        mfma_written = {}                      # reg -> index of the MFMA that last wrote it
+        valu_written = {}                      # reg -> index of the VALU instruction that last wrote it
+        mfma_read_ab = {}                      # reg -> count of MFMAs issued when an MFMA last read it as A/B
+        n_mfma = 0
+        for idx, (op, ops) in enumerate(loop):
+            if op == "s_waitcnt":
+                m = re.search(r"lgkmcnt\((\d+)\)", " ".join(ops))
+                if m:
+                    keep = int(m.group(1))
+                    while len(pending) > keep:
+                        for r in pending.popleft():
+                            inflight.discard(r)
+                continue
+            if op in ("s_barrier",) or op.startswith("s_"):
+                continue
+            dst = regs(ops[0]) if ops else []
+            srcs = [r for o in ops[1:] for r in regs(o)]
+            if op.startswith("ds_read"):
+                addr = regs(ops[1])
+                for r in addr:
+                    if r in inflight:
+                        print(f"   [1] {op} address v{r} still in flight (#{idx})"); bad += 1
+                for r in dst:
+                    if r in mfma_read_ab and n_mfma - mfma_read_ab[r] < 1:
+                        print(f"   [4] {op} lands in v{r}, read by the MFMA issued just before (#{idx})"); bad += 1
+                pending.append(dst)
+                inflight.update(dst)
+                continue
+            if op.startswith("buffer_load"):
+                srcs = regs(ops[0])
+                dst = []
+            for r in srcs + (dst if not op.startswith("v_mfma") else []):
+                if r in inflight:
+                    print(f"   [1] {op} touches v{r} while its LDS read is in flight (#{idx})"); bad += 1
+            if op.startswith("v_mfma"):
+                for r in srcs:
+                    if r in valu_written and idx - valu_written[r] < 3:      # >= 2 instructions strictly between
+                        print(f"   [2] {op} reads v{r} written by a VALU instruction {idx - valu_written[r] - 1} instructions earlier (#{idx})"); bad += 1
+                for r in regs(ops[1]) + regs(ops[2]):
+                    mfma_read_ab[r] = n_mfma + 1
+                n_mfma += 1
+                for r in dst:
+                    mfma_written[r] = idx
+                continue
+            for r in srcs + dst:
+                if r in mfma_written and idx - mfma_written[r] < 13:
+                    print(f"   [3] {op} touches v{r}, an MFMA result only {idx - mfma_written[r] - 1} instructions old (#{idx})"); bad += 1
+            if op.startswith("v_") and not op.startswith("v_cmp"):
+                for r in dst:
+                    valu_written[r] = idx
+        if pending and False:
+            pass
+        branches = [i for i, (op, _) in enumerate(loop) if "branch" in op]
+        print(f"   branches inside the loop: {len(branches)} (the two exit tests per tile); findings: {bad}")
+    if not found:
+        print("no hand-scheduled tile loop found in", obj)
+        sys.exit(2)
+    sys.exit(1 if bad else 0)
+
+
+main()

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Generates tiny-flash-attention_amd/csrc/tfa_fwd_il_asm_loop.inc: the steady-state tile loop of the il8 forward kernel (bf16, D = 128, the
+headline instantiation) as ONE hand-written basic block per tile, with a fixed register map — what hipcc's schedule of the same work is
+320 instructions per tile in three blocks plus glue (profiles/r05_loop_stats.txt).
+
+    python tools/gen_il_asm_loop.py > tiny-flash-attention_amd/csrc/tfa_fwd_il_asm_loop.inc
+
+The loop runs tiles j, j+1, ... of a pass while the next tile exists, needs no mask and no row of the wave has outgrown its reference exponent (the
+lazy-reference rule of tfa_fwd_kernel_il.h); it leaves with j = the first tile it did not process, S(j) in sA (j even) / sB (j odd) and that tile's
+half-wave row maximum in `mx`.  Same arithmetic, same order per partial sum as the compiler-scheduled body: bits identical (tools/ab_multi.py --check).
+
+Registers: every operand is the compiler's choice (generic "v" / "s" constraints — fixed physical registers made hipcc copy 96 registers in and out and
+spill 57: the first version).  The kernel is compiled with amdgpu_num_vgpr(96) = 192 allocator-owned registers; O lives in v[192:255], tfa_fwd_il_regs.h.
+  sa0, sa1   S of even tiles, two 16-register MFMA accumulators (element e of a tile is register e of the pair); P is formed IN PLACE:
+             x = fma(s, c, -mref) -> exp2 -> the packed 16-bit pair (2k, 2k+1) of P slot s lands in register 8s + k, so a slot's four
+             registers are the PV MFMA's B operand without a move (hipcc's version needs 16 + ~10 more registers for pw / xs)
+  sb0, sb1   S of odd tiles
+  q0..q7     the eight k-slot fragments of the wave's rows (MFMA B operands of S^T = K Q^T)
+  f0..f3     fragment buffers: K fragments by ds_read_b128, V fragments by two ds_read_b64_tr_b16, read in PAIRS two MFMAs ahead (one s_waitcnt per pair)
+  l0..l3     four interleaved partial row sums;  mref (input), thr = mref + 8, tmp;  ma / mb: half-wave row maximum of the even / odd tile a body produced
+  ka         K fragment addresses of k-slots 1..7 (kaddr ^ (slot << 5); slot 0 is kaddr itself);  va: V fragment base
+  ks0, ks1, vs0, vs1   lane offsets of this wave's two K and two V LDS-DMA pieces; koff / voff (scalars): byte offset of the tile to request, advanced per tile
+Single registers of a tuple are reached through assembler symbols (SA0, ... KA) that .irpc blocks at the top parse out of the operand strings.
+"""
+import sys
+
+N1, N2, DT = 16, 16, 4
+NE1 = 21
+TILE = 16384
+import os
+NBUF = int(os.environ.get("TFA_GEN_NBUF", "4"))    # experiment knob: fewer fragment buffers (WRONG results below 4 with this schedule: register-pressure probe only)
+
+# operands whose register NUMBER the text needs (sub-registers of a tuple, or single registers used inside v[..] expressions): name -> asm symbol
+PARSED = {"sa0": "SA0", "sa1": "SA1", "sb0": "SB0", "sb1": "SB1", "l0": "L0", "l1": "L1", "l2": "L2", "l3": "L3",
+          "f0": "F0", "f1": "F1", "f2": "F2", "f3": "F3", "ka": "KA"}
+KADDR = {0: "%[kaddr]", 1: "v[KA+0]", 2: "v[KA+1]", 3: "v[KA+2]", 4: "v[KA+3]", 5: "%[ka5]", 6: "%[ka6]", 7: "%[ka7]"}
+
+
+def parse_block(op, sym):
+    """assembler directives that set symbol `sym` to the number of the first register of inline-asm operand %[op] ("v[12:27]" or "v5")"""
+    return [f".set {sym}, 0", ".set _tfa_pd, 0", f'.irpc c, "%[{op}]"', ".ifc \\c, :", ".set _tfa_pd, 1", ".endif", ".if _tfa_pd == 0",
+            ".irp d,0,1,2,3,4,5,6,7,8,9", ".ifc \\c, \\d", f".set {sym}, {sym}*10+\\d", ".endif", ".endr", ".endif", ".endr"]
+
+
+def slot_of_elem(e):
+    return 1 + (e * N1 // NE1 if e < NE1 else N1 + (e - NE1) * (3 * DT - 1) // (32 - NE1))
+
+
+def S(cur, e, n=1):
+    """register(s) of S element e (0..31) of the tile set `cur` ('a' or 'b'): two 16-register tuples"""
+    base = ("SA" if cur == "a" else "SB") + ("0" if e < 16 else "1")
+    off = e & 15
+    return f"v[{base}+{off}]" if n == 1 else f"v[{base}+{off}:{base}+{off + n - 1}]"
+
+
+def Sfull(cur, half):
+    return f"%[s{cur}{half}]"
+
+
+def frag(g, n=4, sub=0):
+    b = f"F{g % NBUF}"
+    return f"%[f{g % NBUF}]" if (n == 4 and sub == 0) else f"v[{b}+{sub}:{b}+{sub + n - 1}]"
+
+
+def frag_reads(g, par):
+    """ds_read instructions that bring fragment g (0..31) of the tile body into buffer g % 4"""
+    if g < N1:
+        kt, ks = g & 1, g >> 1
+        off = (par ^ 1) * TILE + kt * 8192
+        return [f"ds_read_b128 {frag(g)}, {KADDR[ks]} offset:{off}"]
+    i = g - N1
+    off = (2 + par) * TILE + (i // DT) * 4096 + (i % DT) * 512
+    return [f"ds_read_b64_tr_b16 {frag(g, 2, 0)}, %[va] offset:{off}",
+            f"ds_read_b64_tr_b16 {frag(g, 2, 2)}, %[va] offset:{off + 256}"]
+
+
+def body(par, lbl):
+    cur, nxt = ("a", "b") if par == 0 else ("b", "a")
+    o = []
+    a = o.append
+    a(f"; ---- tile of parity {par}: S(j) in s{cur} -> P, O += P V(j); S(j+1) = K(j+1) Q^T -> s{nxt}")
+    # fragments travel in pairs: at an even slot g fragment g+2 is requested in FRONT of the wait + MFMA g and fragment g+3 BEHIND MFMA g, so that a read
+    # never lands in the buffer of the MFMA issued just before it (one MFMA of distance, what hipcc's own schedule keeps) and one s_waitcnt serves two MFMAs
+    for g in (0, 1):
+        o.extend(frag_reads(g, par))
+    post = []
+    for g in range(N1 + N2):
+        if g % 2 == 0:
+            cnt = 0
+            if g + 2 < N1 + N2:
+                rs = frag_reads(g + 2, par)
+                o.extend(rs)
+                cnt = len(rs)
+            a(f"s_waitcnt lgkmcnt({cnt})")
+            post = frag_reads(g + 3, par) if g + 3 < N1 + N2 else []
+        if g < N1:
+            kt, ks = g & 1, g >> 1
+            c = "0" if ks == 0 else Sfull(nxt, kt)
+            a(f"v_mfma_f32_32x32x16_bf16 {Sfull(nxt, kt)}, {frag(g)}, %[q{ks}], {c}")
+        else:
+            i = g - N1
+            ob = 192 + 16 * (i % DT)
+            a(f"v_mfma_f32_32x32x16_bf16 v[{ob}:{ob + 15}], {frag(g)}, {S(cur, 8 * (i // DT), 4)}, v[{ob}:{ob + 15}]")
+        # LDS-DMA pieces behind the first four MFMAs: V(j+1) -> V buffer par^1, K(j+2) -> K buffer par (m0 write, one VALU as its wait state, the load)
+        if g % 2 == 0:
+            o.extend(post)
+        # (source offset = the piece's lane offset + the tile's byte offset, kept in a scalar that advances by the tile stride; the address register is a
+        #  scratch one — the row-max register of the tile being produced, dead until part 2 — a load has read it by the time the next instruction issues)
+        if g < 2:
+            a(f"s_add_u32 m0, %[ldsw], {(2 + (par ^ 1)) * TILE + g * 1024}")
+            a(f"v_add_u32 %[m{nxt}], %[voff], %[vs{g}]")
+            a(f"buffer_load_dwordx4 %[m{nxt}], %[vrs], 0 offen lds")
+        elif g < 4:
+            a(f"s_add_u32 m0, %[ldsw], {par * TILE + (g - 2) * 1024}")
+            a(f"v_add_u32 %[m{nxt}], %[koff], %[ks{g - 2}]")
+            a(f"buffer_load_dwordx4 %[m{nxt}], %[krs], 0 offen lds")
+        # this slot's share of tile j's softmax: scale/subtract two slots ahead of an element's own slot, exp2 one ahead, sum + pack in it
+        for e in range(32):
+            if max(slot_of_elem(e) - 2, 0) == g:
+                a(f"v_fma_f32 {S(cur, e)}, {S(cur, e)}, %[sc], -%[mref]")
+        for e in range(32):
+            if slot_of_elem(e) - 1 == g:
+                a(f"v_exp_f32 {S(cur, e)}, {S(cur, e)}")
+        for e in range(32):
+            if slot_of_elem(e) == g:
+                a(f"v_add_f32 v[L{e & 3}], v[L{e & 3}], {S(cur, e)}")
+                if e & 1:
+                    s, k = e >> 3, (e & 7) >> 1
+                    a(f"v_cvt_pk_bf16_f32 {S(cur, 8 * s + k)}, {S(cur, e - 1)}, {S(cur, e)}")
+        if g >= N1:                                        # row max of S(j+1): two elements per slot
+            q = g - N1
+            if q == 0:
+                a(f"v_max_f32 %[m{nxt}], {S(nxt, 0)}, {S(nxt, 1)}")
+            else:
+                a(f"v_max3_f32 %[m{nxt}], %[m{nxt}], {S(nxt, 2 * q)}, {S(nxt, 2 * q + 1)}")
+    a("s_waitcnt vmcnt(0)")
+    a("s_barrier")
+    a("s_add_u32 %[j], %[j], 1")
+    a("s_add_u32 %[koff], %[koff], %[kstr]")
+    a("s_add_u32 %[voff], %[voff], %[vstr]")
+    a("s_cmp_ge_i32 %[j], %[jend]")
+    a(f"v_mul_f32 v[F0], %[sc], %[m{nxt}]")            # (the fragment buffers are dead behind the last MFMA)
+    a(f"s_cbranch_scc1 {lbl}_exit%=")
+    a("v_cmp_gt_f32 vcc, v[F0], %[thr]")
+    a(f"s_cbranch_vccnz {lbl}_exit%=")
+    return o
+
+
+def main():
+    lines = []
+    a = lines.append
+    for op, sym in PARSED.items():
+        lines.extend(parse_block(op, sym))
+    for s in range(1, 8):
+        a(f"v_xor_b32 {KADDR[s]}, {s << 5}, %[kaddr]")
+    a("v_add_f32 %[thr], 0x41000000, %[mref]")
+    a("il_loop%=:")
+    lines.extend(body(0, "il"))
+    lines.extend(body(1, "il"))
+    a("s_branch il_loop%=")
+    a("il_exit%=:")
+    # checks on the schedule itself
+    for s in range(4):
+        assert slot_of_elem(8 * s + 7) < N1 + DT * s, "a P slot is packed too late for the PV MFMA that reads it"
+    n_tile = sum(1 for l in body(0, "x") if not l.startswith(";"))
+    out = []
+    out.append("// tfa_fwd_il_asm_loop.inc — GENERATED by tools/gen_il_asm_loop.py (do not edit; re-generate).  The steady-state tile loop of fwd_kernel_il's")
+    out.append("// headline instantiation (bf16, D = 128, 8 waves, lazy row reference) as hand-scheduled gfx950 assembly: ONE basic block of "
+               f"{n_tile} instructions per tile")
+    out.append("// (32 MFMA, 128 + 6 VALU, 48 LDS reads, 4 LDS-DMA, 17 s_waitcnt, 12 scalar) where hipcc's schedule of the same work is ~320 in three blocks plus glue.")
+    out.append("// Registers are the COMPILER's choice (generic constraints): the text reaches single registers of a tuple through assembler symbols that the")
+    out.append("// leading .irpc blocks parse out of the operand strings (\"v[12:27]\" -> 12).  Rules and layout: the generator's docstring.")
+    out.append("#define TFA_IL_ASM_LOOP \\")
+    for l in lines:
+        if l.startswith(";"):
+            continue
+        esc = l.replace("\\", "\\\\").replace('"', '\\"')
+        out.append(f'  "{esc}\\n\\t" \\')
+    out.append('  ""')
+    out.append(f"#define TFA_IL_ASM_LOOP_INSTR_PER_TILE {n_tile}")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
