@@ -69,7 +69,11 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
 
 }  // namespace tfa
 #include "tfa_fwd_il_regs.h"
+#if defined(TFA_IL_ASM_INC)        // an A/B arm of the generated loop (tools/gen_il_asm_loop.py with TFA_GEN_* knobs; tools/r5_arm.sh)
+#include TFA_IL_ASM_INC
+#else
 #include "tfa_fwd_il_asm_loop.inc"
+#endif
 #if !defined(TFA_IL_USE_ASMLOOP)
 #define TFA_IL_USE_ASMLOOP 1     // 0: the compiler-scheduled body everywhere (the A/B arm of the hand-scheduled steady state, tools/r5_arm.sh)
 #endif
@@ -319,10 +323,11 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     if (with_dma && ntx > 1) dma_k(one, 1);
     auto q_rs = slice_rsrc(qbase, p.q_bytes, (unsigned long long)q0x * (unsigned long long)p.qs_n * 2ull);
     // (the half-wave index goes through an empty asm: otherwise hipcc hoists the eight per-k-slot offsets out of the pass loop, where they stay live
-    //  across the tile loop — eight registers the loop does not have, round 5)
-    int hix = hi;
+    //  across the tile loop — eight registers the loop does not have, round 5 — and the lane id is re-derived with v_mbcnt instead of kept from the start)
+    const int lane_p = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (the lane id re-derived, like the epilogue does)
+    int hix = lane_p >> 5;
     asm volatile("" : "+v"(hix));
-    const int qoff = ((WIN ? 0 : q0x) + wrow * 32 + qi) * (int)p.qs_n * 2 + hix * 16;
+    const int qoff = ((WIN ? 0 : q0x) + wrow * 32 + (lane_p & 31)) * (int)p.qs_n * 2 + hix * 16;
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
       u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(q_rs, (2 * s + hix) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB, 0, 0);

@@ -51,6 +51,8 @@ def main():
             if m.group(1).startswith("_Z") or cur is None:      # (local labels of an asm statement — il_loop0, il_exit0 — belong to the kernel around them)
                 cur = m.group(1)
                 kernels[cur] = []
+            else:
+                kernels[cur].append(("label", [m.group(1)]))
             continue
         if cur is not None and line.startswith("\t"):
             p = parse(line)
@@ -61,15 +63,15 @@ def main():
         if pat not in name:
             continue
         # the loop: seven consecutive v_xor_b32 (K addresses), a v_add_f32 (thr), then bodies up to the backward s_branch
-        start = None
-        for i in range(len(ins) - 8):
-            if all(ins[i + k][0].startswith("v_xor_b32") for k in range(7)) and ins[i + 7][0].startswith("v_add_f32"):
-                start = i + 8
-                break
-        if start is None:
+        # the loop lies between the asm statement's own labels: il_loop<N> .. il_exit<N> (lazy reference), the first ix_b.. label's exact_step .. ix_exit<N>
+        labels = [(i, o[0]) for i, (op, o) in enumerate(ins) if op == "label"]
+        first = next((i for i, n in labels if n.startswith("il_loop") or n.startswith("ix_b")), None)
+        last = next((i for i, n in labels if n.startswith("il_exit") or n.startswith("ix_exit")), None)
+        if first is None or last is None:
             continue
-        end = next(i for i in range(start, len(ins)) if ins[i][0] == "s_branch")
-        loop = ins[start:end]
+        if any(n.startswith("ix_b") for _, n in labels):
+            first = max(i for i in range(first) if ins[i][0].startswith("v_xor_b32")) + 1     # the exact loop starts with the first tile's exact_step
+        loop = [x for x in ins[first:last] if x[0] != "label"]
         found += 1
         n_tiles = sum(1 for op, _ in loop if op == "s_barrier")
         mix = collections.Counter()
@@ -94,6 +96,8 @@ def main():
                         for r in pending.popleft():
                             inflight.discard(r)
                 continue
+            if op.startswith("s_") and "branch" in op and not op.startswith("s_cbranch_scc1") and False:
+                pass
             if op in ("s_barrier",) or op.startswith("s_"):
                 continue
             dst = regs(ops[0]) if ops else []
@@ -134,7 +138,7 @@ def main():
         if pending and False:
             pass
         branches = [i for i, (op, _) in enumerate(loop) if "branch" in op]
-        print(f"   branches inside the loop: {len(branches)} (the two exit tests per tile); findings: {bad}")
+        print(f"   branches inside the loop: {len(branches)}; findings: {bad}")
     if not found:
         print("no hand-scheduled tile loop found in", obj)
         sys.exit(2)

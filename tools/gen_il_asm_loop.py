@@ -24,10 +24,12 @@ Single registers of a tuple are reached through assembler symbols (SA0, ... KA) 
 """
 import sys
 
-N1, N2, DT = 16, 16, 4
-NE1 = 21
-TILE = 16384
 import os
+N1, N2, DT = 16, 16, 4
+NE1 = int(os.environ.get("TFA_GEN_NE1", "21"))             # softmax elements summed / packed behind the QK^T MFMAs (of 32); the rest behind the PV MFMAs
+DMA0 = int(os.environ.get("TFA_GEN_DMA0", "0"))            # first of the four MFMA slots that carry an LDS-DMA piece
+EXPD = int(os.environ.get("TFA_GEN_EXPD", "1"))            # an element's exp2 is issued EXPD slots, its scale/subtract 2 * EXPD slots ahead of its sum/pack slot
+TILE = 16384
 NBUF = int(os.environ.get("TFA_GEN_NBUF", "4"))    # experiment knob: fewer fragment buffers (WRONG results below 4 with this schedule: register-pressure probe only)
 
 # operands whose register NUMBER the text needs (sub-registers of a tuple, or single registers used inside v[..] expressions): name -> asm symbol
@@ -74,7 +76,7 @@ def frag_reads(g, par):
             f"ds_read_b64_tr_b16 {frag(g, 2, 2)}, %[va] offset:{off + 256}"]
 
 
-def body(par, lbl):
+def body(par, lbl, exact=False, resc=False):
     cur, nxt = ("a", "b") if par == 0 else ("b", "a")
     o = []
     a = o.append
@@ -106,20 +108,24 @@ def body(par, lbl):
             o.extend(post)
         # (source offset = the piece's lane offset + the tile's byte offset, kept in a scalar that advances by the tile stride; the address register is a
         #  scratch one — the row-max register of the tile being produced, dead until part 2 — a load has read it by the time the next instruction issues)
-        if g < 2:
-            a(f"s_add_u32 m0, %[ldsw], {(2 + (par ^ 1)) * TILE + g * 1024}")
-            a(f"v_add_u32 %[m{nxt}], %[voff], %[vs{g}]")
+        gd = g - DMA0
+        if 0 <= gd < 2:
+            a(f"s_add_u32 m0, %[ldsw], {(2 + (par ^ 1)) * TILE + gd * 1024}")
+            a(f"v_add_u32 %[m{nxt}], %[voff], %[vs{gd}]")
             a(f"buffer_load_dwordx4 %[m{nxt}], %[vrs], 0 offen lds")
-        elif g < 4:
-            a(f"s_add_u32 m0, %[ldsw], {par * TILE + (g - 2) * 1024}")
-            a(f"v_add_u32 %[m{nxt}], %[koff], %[ks{g - 2}]")
+        elif 2 <= gd < 4:
+            a(f"s_add_u32 m0, %[ldsw], {par * TILE + (gd - 2) * 1024}")
+            a(f"v_add_u32 %[m{nxt}], %[koff], %[ks{gd - 2}]")
             a(f"buffer_load_dwordx4 %[m{nxt}], %[krs], 0 offen lds")
+        if resc and g < N1:                                # the re-basing body: O *= alpha rides behind the QK^T MFMAs, one register quad per MFMA
+            for k in range(4):
+                a(f"v_mul_f32 v{192 + 4 * g + k}, v{192 + 4 * g + k}, %[alpha]")
         # this slot's share of tile j's softmax: scale/subtract two slots ahead of an element's own slot, exp2 one ahead, sum + pack in it
         for e in range(32):
-            if max(slot_of_elem(e) - 2, 0) == g:
+            if max(slot_of_elem(e) - 2 * EXPD, 0) == g:
                 a(f"v_fma_f32 {S(cur, e)}, {S(cur, e)}, %[sc], -%[mref]")
         for e in range(32):
-            if slot_of_elem(e) - 1 == g:
+            if max(slot_of_elem(e) - EXPD, 0) == g:
                 a(f"v_exp_f32 {S(cur, e)}, {S(cur, e)}")
         for e in range(32):
             if slot_of_elem(e) == g:
@@ -139,45 +145,83 @@ def body(par, lbl):
     a("s_add_u32 %[koff], %[koff], %[kstr]")
     a("s_add_u32 %[voff], %[voff], %[vstr]")
     a("s_cmp_ge_i32 %[j], %[jend]")
-    a(f"v_mul_f32 v[F0], %[sc], %[m{nxt}]")            # (the fragment buffers are dead behind the last MFMA)
-    a(f"s_cbranch_scc1 {lbl}_exit%=")
-    a("v_cmp_gt_f32 vcc, v[F0], %[thr]")
-    a(f"s_cbranch_vccnz {lbl}_exit%=")
+    if not exact:
+        a(f"v_mul_f32 v[F0], %[sc], %[m{nxt}]")            # (the fragment buffers are dead behind the last MFMA)
+        a(f"s_cbranch_scc1 {lbl}_exit%=")
+        a("v_cmp_gt_f32 vcc, v[F0], %[thr]")
+        a(f"s_cbranch_vccnz {lbl}_exit%=")
+    else:
+        a(f"s_cbranch_scc1 {lbl}_exit%=")
+        o.extend(exact_step(nxt, lbl))
     return o
 
 
-def main():
-    lines = []
-    a = lines.append
-    for op, sym in PARSED.items():
-        lines.extend(parse_block(op, sym))
-    for s in range(1, 8):
-        a(f"v_xor_b32 {KADDR[s]}, {s << 5}, %[kaddr]")
-    a("v_add_f32 %[thr], 0x41000000, %[mref]")
-    a("il_loop%=:")
-    lines.extend(body(0, "il"))
-    lines.extend(body(1, "il"))
-    a("s_branch il_loop%=")
-    a("il_exit%=:")
-    # checks on the schedule itself
-    for s in range(4):
-        assert slot_of_elem(8 * s + 7) < N1 + DT * s, "a P slot is packed too late for the PV MFMA that reads it"
-    n_tile = sum(1 for l in body(0, "x") if not l.startswith(";"))
-    out = []
-    out.append("// tfa_fwd_il_asm_loop.inc — GENERATED by tools/gen_il_asm_loop.py (do not edit; re-generate).  The steady-state tile loop of fwd_kernel_il's")
-    out.append("// headline instantiation (bf16, D = 128, 8 waves, lazy row reference) as hand-scheduled gfx950 assembly: ONE basic block of "
-               f"{n_tile} instructions per tile")
-    out.append("// (32 MFMA, 128 + 6 VALU, 48 LDS reads, 4 LDS-DMA, 17 s_waitcnt, 12 scalar) where hipcc's schedule of the same work is ~320 in three blocks plus glue.")
-    out.append("// Registers are the COMPILER's choice (generic constraints): the text reaches single registers of a tuple through assembler symbols that the")
-    out.append("// leading .irpc blocks parse out of the operand strings (\"v[12:27]\" -> 12).  Rules and layout: the generator's docstring.")
-    out.append("#define TFA_IL_ASM_LOOP \\")
+def exact_step(t, lbl):
+    """The exact running maximum advanced to the tile whose S is in set `t` (half-wave row maximum in m<t>): both half-waves' maxima combined
+    (v_permlane32_swap), nref = max(mref, max * c); alpha = exp2(mref - nref); mref = nref; l *= alpha; then on to that tile's body — the one that
+    also re-bases O when some row of the wave moved (alpha != 1 somewhere), the plain one otherwise.  Scratch: the (dead) fragment buffers."""
+    par = 0 if t == "a" else 1
+    return [f"v_mov_b32 v[F0], %[m{t}]", f"v_mov_b32 v[F0+1], %[m{t}]", "s_nop 1", "v_permlane32_swap_b32 v[F0], v[F0+1]",
+            "v_max_f32 v[F0], v[F0], v[F0+1]", "v_mul_f32 v[F0], %[sc], v[F0]", "v_max_f32 v[F0], %[mref], v[F0]",
+            "v_cmp_neq_f32 vcc, v[F0], %[mref]", "v_sub_f32 v[F0+1], %[mref], v[F0]", "v_mov_b32 %[mref], v[F0]", "v_exp_f32 %[alpha], v[F0+1]",
+            f"s_cbranch_vccz {lbl}_b{par}n%=",
+            # some row moved: the row sums take the factor here, O inside the body
+            "s_nop 0", "v_mul_f32 v[L0], v[L0], %[alpha]", "v_mul_f32 v[L1], v[L1], %[alpha]", "v_mul_f32 v[L2], v[L2], %[alpha]", "v_mul_f32 v[L3], v[L3], %[alpha]",
+            f"s_branch {lbl}_b{par}r%="]
+
+
+def emit(name, lines, n_tile, what):
+    out = [f"#define {name} \\"]
     for l in lines:
         if l.startswith(";"):
             continue
         esc = l.replace("\\", "\\\\").replace('"', '\\"')
         out.append(f'  "{esc}\\n\\t" \\')
     out.append('  ""')
-    out.append(f"#define TFA_IL_ASM_LOOP_INSTR_PER_TILE {n_tile}")
+    out.append(f"#define {name}_INSTR_PER_TILE {n_tile}    // {what}")
+    return out
+
+
+def main():
+    for s in range(4):
+        assert slot_of_elem(8 * s + 7) < N1 + DT * s, "a P slot is packed too late for the PV MFMA that reads it"
+    head = []
+    for op, sym in PARSED.items():
+        head.extend(parse_block(op, sym))
+    for s in range(1, 8):
+        head.append(f"v_xor_b32 {KADDR[s]}, {s << 5}, %[kaddr]")
+    # ---- the lazy-reference loop (the headline kernel)
+    lines = list(head)
+    a = lines.append
+    a("v_add_f32 %[thr], 0x41000000, %[mref]")
+    a("il_loop%=:")
+    lines.extend(body(0, "il"))
+    lines.extend(body(1, "il"))
+    a("s_branch il_loop%=")
+    a("il_exit%=:")
+    n_tile = sum(1 for l in body(0, "x") if not l.startswith(";"))
+    # ---- the exact-running-max loop (VF_IL_EXACT, variant 38): per parity a plain body and one that also re-bases O; every body ends in the
+    # exact_step of the tile it produced, which picks the next body
+    xl = list(head)
+    a = xl.append
+    xl.extend(exact_step("a", "ix"))
+    for par in (0, 1):
+        for resc in (False, True):
+            a(f"ix_b{par}{'r' if resc else 'n'}%=:")
+            xl.extend(body(par, "ix", exact=True, resc=resc))
+    a("ix_exit%=:")
+    n_x = sum(1 for l in body(0, "x", exact=True, resc=True) if not l.startswith(";"))
+    n_xn = sum(1 for l in body(0, "x", exact=True, resc=False) if not l.startswith(";"))
+    out = []
+    out.append("// tfa_fwd_il_asm_loop.inc — GENERATED by tools/gen_il_asm_loop.py (do not edit; re-generate).  The steady-state tile loop of fwd_kernel_il's")
+    out.append("// headline instantiation (bf16, D = 128, 8 waves, lazy row reference) as hand-scheduled gfx950 assembly: ONE basic block of "
+               f"{n_tile} instructions per tile")
+    out.append("// (32 MFMA, 128 + 6 VALU, 48 LDS reads, 4 LDS-DMA, 17 s_waitcnt, 12 scalar) where hipcc's schedule of the same work is ~320 in three blocks plus glue;")
+    out.append(f"// and the same for the exact-running-max instantiation (variant 38): {n_xn} instructions per tile, {n_x} in the body that also re-bases O.")
+    out.append("// Registers are the COMPILER's choice (generic constraints): the text reaches single registers of a tuple through assembler symbols that the")
+    out.append("// leading .irpc blocks parse out of the operand strings (\"v[12:27]\" -> 12).  Rules and layout: the generator's docstring.")
+    out.extend(emit("TFA_IL_ASM_LOOP", lines, n_tile, "lazy row reference"))
+    out.extend(emit("TFA_IL_ASM_LOOP_EXACT", xl, n_x, "exact running maximum, the re-basing body"))
     print("\n".join(out))
 
 
