@@ -74,6 +74,27 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
 #else
 #include "tfa_fwd_il_asm_loop.inc"
 #endif
+// the two asm statements of the hand-scheduled loops (operands = the kernel's locals; the text differs per dtype: tfa_fwd_il_tile_loop.inc picks it)
+#define TFA_IL_ASM_LAZY_STMT(TEXT) \
+  asm volatile(TEXT \
+  : [sa0] "+v"(sA[0]), [sa1] "+v"(sA[1]), [sb0] "+v"(sB[0]), [sb1] "+v"(sB[1]), \
+  [l0] "+v"(l4[0]), [l1] "+v"(l4[1]), [l2] "+v"(l4[2]), [l3] "+v"(l4[3]), [ma] "+v"(mA), [mb] "+v"(mB), [j] "+s"(j), \
+  [koff] "+s"(koff), [voff] "+s"(voff), \
+  [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2), [f3] "=&v"(f3), [ka] "=&v"(ka), [ka5] "=&v"(ka5), [ka6] "=&v"(ka6), [ka7] "=&v"(ka7), [thr] "=&v"(thr) \
+  : [q0] "v"(qf[0]), [q1] "v"(qf[1]), [q2] "v"(qf[2]), [q3] "v"(qf[3]), [q4] "v"(qf[4]), [q5] "v"(qf[5]), [q6] "v"(qf[6]), [q7] "v"(qf[7]), \
+  [mref] "v"(mref), [kaddr] "v"(k_rd_addr), [va] "v"(vaddr), [ks0] "v"(k_src[0]), [ks1] "v"(k_src[1]), [vs0] "v"(v_src[0]), [vs1] "v"(v_src[1]), \
+  [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend) \
+  : TFA_O_CLOB0, TFA_O_CLOB1, TFA_O_CLOB2, TFA_O_CLOB3, "m0", "vcc", "scc", "memory")
+#define TFA_IL_ASM_EXACT_STMT(TEXT) \
+  asm volatile(TEXT \
+  : [sa0] "+v"(sA[0]), [sa1] "+v"(sA[1]), [sb0] "+v"(sB[0]), [sb1] "+v"(sB[1]), \
+  [l0] "+v"(l4[0]), [l1] "+v"(l4[1]), [l2] "+v"(l4[2]), [l3] "+v"(l4[3]), [ma] "+v"(mA), [mb] "+v"(mB), [mref] "+v"(mref), [j] "+s"(j), \
+  [koff] "+s"(koff), [voff] "+s"(voff), \
+  [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2), [f3] "=&v"(f3), [ka] "=&v"(ka), [ka5] "=&v"(ka5), [ka6] "=&v"(ka6), [ka7] "=&v"(ka7), [alpha] "=&v"(alpha) \
+  : [q0] "v"(qf[0]), [q1] "v"(qf[1]), [q2] "v"(qf[2]), [q3] "v"(qf[3]), [q4] "v"(qf[4]), [q5] "v"(qf[5]), [q6] "v"(qf[6]), [q7] "v"(qf[7]), \
+  [kaddr] "v"(k_rd_addr), [va] "v"(vaddr), [ks0] "v"(k_src[0]), [ks1] "v"(k_src[1]), [vs0] "v"(v_src[0]), [vs1] "v"(v_src[1]), \
+  [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend) \
+  : TFA_O_CLOB0, TFA_O_CLOB1, TFA_O_CLOB2, TFA_O_CLOB3, "m0", "vcc", "scc", "memory")
 #if !defined(TFA_IL_USE_ASMLOOP)
 #define TFA_IL_USE_ASMLOOP 1     // 0: the compiler-scheduled body everywhere (the A/B arm of the hand-scheduled steady state, tools/r5_arm.sh)
 #endif

@@ -30,6 +30,8 @@ NE1 = int(os.environ.get("TFA_GEN_NE1", "21"))             # softmax elements su
 DMA0 = int(os.environ.get("TFA_GEN_DMA0", "0"))            # first of the four MFMA slots that carry an LDS-DMA piece
 EXPD = int(os.environ.get("TFA_GEN_EXPD", "1"))            # an element's exp2 is issued EXPD slots, its scale/subtract 2 * EXPD slots ahead of its sum/pack slot
 TILE = 16384
+MFMA = "v_mfma_f32_32x32x16_bf16"                          # set per dtype by main()
+CVT = "v_cvt_pk_bf16_f32"
 NBUF = int(os.environ.get("TFA_GEN_NBUF", "4"))    # experiment knob: fewer fragment buffers (WRONG results below 4 with this schedule: register-pressure probe only)
 
 # operands whose register NUMBER the text needs (sub-registers of a tuple, or single registers used inside v[..] expressions): name -> asm symbol
@@ -98,11 +100,11 @@ def body(par, lbl, exact=False, resc=False):
         if g < N1:
             kt, ks = g & 1, g >> 1
             c = "0" if ks == 0 else Sfull(nxt, kt)
-            a(f"v_mfma_f32_32x32x16_bf16 {Sfull(nxt, kt)}, {frag(g)}, %[q{ks}], {c}")
+            a(f"{MFMA} {Sfull(nxt, kt)}, {frag(g)}, %[q{ks}], {c}")
         else:
             i = g - N1
             ob = 192 + 16 * (i % DT)
-            a(f"v_mfma_f32_32x32x16_bf16 v[{ob}:{ob + 15}], {frag(g)}, {S(cur, 8 * (i // DT), 4)}, v[{ob}:{ob + 15}]")
+            a(f"{MFMA} v[{ob}:{ob + 15}], {frag(g)}, {S(cur, 8 * (i // DT), 4)}, v[{ob}:{ob + 15}]")
         # LDS-DMA pieces behind the first four MFMAs: V(j+1) -> V buffer par^1, K(j+2) -> K buffer par (m0 write, one VALU as its wait state, the load)
         if g % 2 == 0:
             o.extend(post)
@@ -132,7 +134,7 @@ def body(par, lbl, exact=False, resc=False):
                 a(f"v_add_f32 v[L{e & 3}], v[L{e & 3}], {S(cur, e)}")
                 if e & 1:
                     s, k = e >> 3, (e & 7) >> 1
-                    a(f"v_cvt_pk_bf16_f32 {S(cur, 8 * s + k)}, {S(cur, e - 1)}, {S(cur, e)}")
+                    a(f"{CVT} {S(cur, 8 * s + k)}, {S(cur, e - 1)}, {S(cur, e)}")
         if g >= N1:                                        # row max of S(j+1): two elements per slot
             q = g - N1
             if q == 0:
@@ -182,9 +184,11 @@ def emit(name, lines, n_tile, what):
     return out
 
 
-def main():
-    for s in range(4):
-        assert slot_of_elem(8 * s + 7) < N1 + DT * s, "a P slot is packed too late for the PV MFMA that reads it"
+def build(dtype):
+    """(lines of the lazy-reference loop, lines of the exact-running-max loop, instructions per tile of each body) for one 16-bit type"""
+    global MFMA, CVT
+    MFMA = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
+    CVT = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
     head = []
     for op, sym in PARSED.items():
         head.extend(parse_block(op, sym))
@@ -212,16 +216,26 @@ def main():
     a("ix_exit%=:")
     n_x = sum(1 for l in body(0, "x", exact=True, resc=True) if not l.startswith(";"))
     n_xn = sum(1 for l in body(0, "x", exact=True, resc=False) if not l.startswith(";"))
+    return lines, xl, n_tile, n_xn, n_x
+
+
+def main():
+    for s in range(4):
+        assert slot_of_elem(8 * s + 7) < N1 + DT * s, "a P slot is packed too late for the PV MFMA that reads it"
+    lines, xl, n_tile, n_xn, n_x = build("bf16")
+    lines_h, xl_h, _, _, _ = build("f16")
     out = []
     out.append("// tfa_fwd_il_asm_loop.inc — GENERATED by tools/gen_il_asm_loop.py (do not edit; re-generate).  The steady-state tile loop of fwd_kernel_il's")
-    out.append("// headline instantiation (bf16, D = 128, 8 waves, lazy row reference) as hand-scheduled gfx950 assembly: ONE basic block of "
+    out.append("// 128-wide 8-wave instantiations (the headline: bf16, lazy row reference; its fp16 twin) as hand-scheduled gfx950 assembly: ONE basic block of "
                f"{n_tile} instructions per tile")
     out.append("// (32 MFMA, 128 + 6 VALU, 48 LDS reads, 4 LDS-DMA, 17 s_waitcnt, 12 scalar) where hipcc's schedule of the same work is ~320 in three blocks plus glue;")
     out.append(f"// and the same for the exact-running-max instantiation (variant 38): {n_xn} instructions per tile, {n_x} in the body that also re-bases O.")
     out.append("// Registers are the COMPILER's choice (generic constraints): the text reaches single registers of a tuple through assembler symbols that the")
     out.append("// leading .irpc blocks parse out of the operand strings (\"v[12:27]\" -> 12).  Rules and layout: the generator's docstring.")
-    out.extend(emit("TFA_IL_ASM_LOOP", lines, n_tile, "lazy row reference"))
-    out.extend(emit("TFA_IL_ASM_LOOP_EXACT", xl, n_x, "exact running maximum, the re-basing body"))
+    out.extend(emit("TFA_IL_ASM_LOOP", lines, n_tile, "bf16, lazy row reference"))
+    out.extend(emit("TFA_IL_ASM_LOOP_F16", lines_h, n_tile, "fp16, lazy row reference"))
+    out.extend(emit("TFA_IL_ASM_LOOP_EXACT", xl, n_x, "bf16, exact running maximum, the re-basing body"))
+    out.extend(emit("TFA_IL_ASM_LOOP_EXACT_F16", xl_h, n_x, "fp16, exact running maximum, the re-basing body"))
     print("\n".join(out))
 
 
