@@ -22,6 +22,10 @@
 #pragma once
 #include <type_traits>
 #include "tfa_fwd_kernel_dma.h"
+#include "tfa_fwd_x4_asm_loop.inc"
+#if !defined(TFA_X4_USE_ASMLOOP)
+#define TFA_X4_USE_ASMLOOP 1     // 0: the compiler-scheduled tile body everywhere (the A/B arm of the hand-scheduled steady state)
+#endif
 
 namespace tfa {
 
@@ -628,11 +632,56 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     // the wave's last tile and re-bases take the slow path.
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
+    // ---- the hand-scheduled steady state (round 5; tfa_fwd_x4_asm_loop.inc, generated by tools/gen_x4_asm_loop.py): the full 256-wide form only (one 32-row
+    // block per wave, all eight column blocks).  Six tile bodies (K ring of three x V pair): entered at a tile j with j % 6 == 0 — the pass's first tile, or
+    // wherever the compiler-scheduled bodies realign after a re-base —, it runs while the next tile exists for the wave, is unmasked, K(j+3) exists and no row
+    // outgrew its reference, and returns the first tile it did not process: S(j) in sA / sB by parity, its half-wave row maximum in mA / mB, the first
+    // two fragments of K(j+1) in kpre.  The ring offsets are then those of tile j (K(t) lives in ring buffer t % 3).
+    constexpr bool ASMX4 = D == 256 && RB == 1 && DVB == 8 && AB == 0 && PF == 2 && PPW == 8 && TFA_X4_USE_ASMLOOP;
+    auto asm_loop = [&](int& j) {
+      if constexpr (ASMX4) {
+        const int lim = fm < nact ? fm : nact;
+        const int jend = (lim - 1 < nt - 3) ? lim - 1 : nt - 3;          // tiles j < jend take the loop
+        int koff = (j + 3) * k_tile_stride, voff = (j + 1) * v_tile_stride;
+        const unsigned vaddr = lds_base + NKB * TILE_BYTES + (unsigned)v_rd_base;
+        const unsigned ldsw = __builtin_amdgcn_readfirstlane(my_piece0);
+        float thr;
+        u32x4 f2, f3;
+        typedef __attribute__((ext_vector_type(16))) unsigned int u32x16;
+        u32x16 ka, kb;
+#define TFA_X4_ASM_STMT(TEXT)                                                                                                                              \
+        asm volatile(TEXT                                                                                                                                  \
+                     : [sa0] "+v"(sA[0][0]), [sa1] "+v"(sA[0][1]), [sb0] "+v"(sB[0][0]), [sb1] "+v"(sB[0][1]),                                            \
+                       [l0] "+v"(l4[0][0]), [l1] "+v"(l4[0][1]), [l2] "+v"(l4[0][2]), [l3] "+v"(l4[0][3]), [ma] "+v"(mA[0]), [mb] "+v"(mB[0]), [j] "+s"(j), \
+                       [koff] "+s"(koff), [voff] "+s"(voff), [f0] "+v"(kpre[0]), [f1] "+v"(kpre[1]),                                                      \
+                       [f2] "=&v"(f2), [f3] "=&v"(f3), [ka] "=&v"(ka), [kb] "=&v"(kb), [thr] "=&v"(thr)                                                    \
+                     : [mref] "v"(mref[0]), [kaddr] "v"(k_rd_addr), [va] "v"(vaddr),                                                                       \
+                       [ks0] "v"(k_src[0]), [ks1] "v"(k_src[1]), [ks2] "v"(k_src[2]), [ks3] "v"(k_src[3]), [ks4] "v"(k_src[4]), [ks5] "v"(k_src[5]),      \
+                       [ks6] "v"(k_src[6]), [ks7] "v"(k_src[7]), [vs0] "v"(v_src[0]), [vs1] "v"(v_src[1]), [vs2] "v"(v_src[2]), [vs3] "v"(v_src[3]),      \
+                       [vs4] "v"(v_src[4]), [vs5] "v"(v_src[5]), [vs6] "v"(v_src[6]), [vs7] "v"(v_src[7]),                                                \
+                       [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend) \
+                     : TFA_X4_ALLCLOB, "m0", "vcc", "scc", "memory")
+        if constexpr (std::is_same<T, __bf16>::value) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP); }
+        else { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_F16); }
+#undef TFA_X4_ASM_STMT
+        kb0 = (unsigned)(j % 3) * TILE_BYTES;
+        kb1 = (unsigned)((j + 1) % 3) * TILE_BYTES;
+        kb2 = (unsigned)((j + 2) % 3) * TILE_BYTES;
+      }
+    };
 #pragma nounroll
     for (int j = 0; j < nact; j += 2) {
-      if (!(dbg & 1) && j + 1 < nact && !trigger(mA)) fused(C0{}, j, sA, sB, mB);
+      bool ring_set = false;
+      if (ASMX4 && !(dbg & 1) && (j % 6) == 0 && j + 1 < nact && j + 1 < fm && j + 3 < nt && !trigger(mA)) {
+        int jj = j;
+        asm_loop(jj);                                  // tiles j .. jj-1 done, jj > j
+        ring_set = true;
+        if (jj & 1) j = jj - 1;                        // on to the odd step below, for tile jj
+        else { j = jj - 2; continue; }                 // back to the even step, for tile jj
+      }
+      else if (!(dbg & 1) && j + 1 < nact && !trigger(mA)) fused(C0{}, j, sA, sB, mB);
       else { if (p.trace && j + 1 < nact) ++n_trig; slow(j, sA, mA, sB, mB); }
-      rotate();
+      if (!ring_set) rotate();
       if (j + 1 >= nact) break;
       if (!(dbg & 1) && j + 2 < nact && !trigger(mB)) fused(C1{}, j + 1, sB, sA, mA);
       else { if (p.trace && j + 2 < nact) ++n_trig; slow(j + 1, sB, mB, sA, mA); }

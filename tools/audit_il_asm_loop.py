@@ -6,7 +6,8 @@ Finds the loop (from its label-less head: the first ds_read_b128 behind the seve
 s_branch) in every kernel that has one and checks, per tile body:
   1. every LDS-read destination is complete (s_waitcnt lgkmcnt, LDS returns in order) before an instruction reads it;
   2. a VALU write of an MFMA A/B/C operand is >= 2 instructions in front of the MFMA;
-  3. an MFMA result is >= 12 instructions old when a non-MFMA instruction reads or overwrites it (8-pass MFMA);
+  3. an MFMA result is >= 12 wait states old when a non-MFMA instruction reads or overwrites it (8-pass MFMA; an instruction between counts 1, an MFMA
+     between counts 8: behind a busy matrix pipe its issue alone takes that long);
   4. an LDS read never lands in a fragment buffer whose MFMA was issued fewer than 1 MFMA ago (the distance hipcc's own schedule keeps);
   5. the block is ONE basic block per tile (no branch targets inside), and reports its instruction mix."""
 import collections
@@ -42,7 +43,7 @@ def parse(line):
 
 def main():
     obj = sys.argv[1]
-    pat = sys.argv[2] if len(sys.argv) > 2 else "fwd_kernel_il"
+    pat = sys.argv[2] if len(sys.argv) > 2 else "fwd_kernel_"
     txt = subprocess.run([OBJDUMP, "-d", obj], stdout=subprocess.PIPE, text=True).stdout
     kernels, cur = collections.OrderedDict(), None
     for line in txt.splitlines():
@@ -65,8 +66,8 @@ def main():
         # the loop: seven consecutive v_xor_b32 (K addresses), a v_add_f32 (thr), then bodies up to the backward s_branch
         # the loop lies between the asm statement's own labels: il_loop<N> .. il_exit<N> (lazy reference), the first ix_b.. label's exact_step .. ix_exit<N>
         labels = [(i, o[0]) for i, (op, o) in enumerate(ins) if op == "label"]
-        first = next((i for i, n in labels if n.startswith("il_loop") or n.startswith("ix_b")), None)
-        last = next((i for i, n in labels if n.startswith("il_exit") or n.startswith("ix_exit")), None)
+        first = next((i for i, n in labels if n.startswith("il_loop") or n.startswith("ix_b") or n.startswith("x4_loop")), None)
+        last = next((i for i, n in labels if n.startswith("il_exit") or n.startswith("ix_exit") or n.startswith("x4_exit")), None)
         if first is None or last is None:
             continue
         if any(n.startswith("ix_b") for _, n in labels):
@@ -130,8 +131,10 @@ def main():
                     mfma_written[r] = idx
                 continue
             for r in srcs + dst:
-                if r in mfma_written and idx - mfma_written[r] < 13:
-                    print(f"   [3] {op} touches v{r}, an MFMA result only {idx - mfma_written[r] - 1} instructions old (#{idx})"); bad += 1
+                if r in mfma_written:
+                    ws = sum(8 if loop[k][0].startswith("v_mfma") else 1 for k in range(mfma_written[r] + 1, idx))
+                    if ws < 12:
+                        print(f"   [3] {op} touches v{r}, an MFMA result only {ws} wait states old (#{idx})"); bad += 1
             if op.startswith("v_") and not op.startswith("v_cmp"):
                 for r in dst:
                     valu_written[r] = idx

@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Generates tiny-flash-attention_amd/csrc/tfa_fwd_x4_asm_loop.inc: the steady-state tile loop of the 256-wide forward kernel (fwd_kernel_x4 with ONE 32-row
+block per wave: head dim 256, four waves, one per SIMD) as hand-scheduled gfx950 assembly — the sibling of tools/gen_il_asm_loop.py.
+
+    python tools/gen_x4_asm_loop.py > tiny-flash-attention_amd/csrc/tfa_fwd_x4_asm_loop.inc
+
+Why: with one wave per SIMD every issued instruction costs the wave 4-5 cycles (docs/LABLOG.md L-9 item 3), and hipcc's schedule of this tile is ~590 instructions
+for 64 MFMAs (2048 cycles of matrix pipe): the loop is issue-bound.  Among the 590: one VALU add per K fragment read (the K ring's buffer offset is a run-time
+value), 64 + 21 scalar instructions, 36 s_nop, 12 v_readlane (SGPR spills), one s_waitcnt per MFMA.  Here:
+  * the K ring (three buffers) and the V pair are unrolled: SIX tile bodies (K(t) in buffer t % 3, V(t) in buffer t % 2, S(t) in sA / sB by t % 2), every LDS
+    address an immediate offset on one of two address sets (buffers 0/1: k-slot address + offset; buffer 2 lies beyond the 16-bit offset field: a second set);
+  * P is formed in place in the S registers (element e = register e of the S pair; P slot s = registers 8s .. 8s+3), as in the il loop;
+  * fragments travel in pairs (one s_waitcnt per two MFMAs), and the stream does not stop at the tile boundary: the first two K fragments of the next tile are
+    requested behind the last PV MFMAs, in front of the barrier (hipcc's `kpre`), so they are the loop's f0 / f1 on entry and on exit;
+  * O lives in a[0:127], Q in a[128:191] (tfa_fwd_kernel_x4.h: hand-owned AccVGPRs) and are named literally; everything else is the compiler's choice
+    (generic operands; single registers of tuples through assembler symbols parsed from the operand strings, see gen_il_asm_loop.py).
+The loop is entered at a tile j with j % 6 == 0, runs while the next tile exists for the wave, is unmasked, K(j+3) exists and no row outgrew its reference;
+it returns the first tile it did not process (any phase): S(j) in sA / sB by parity, its half-wave row maximum in ma / mb, the first two K fragments of
+K(j+1) in f0 / f1.  Same arithmetic, same order as the compiler-scheduled body: bits identical.
+"""
+import os
+
+NKF, NVF, DT = 32, 32, 8                 # K fragments (= S MFMAs), V fragments (= PV MFMAs) per tile, 32-column tiles of O
+N1, N2 = NKF, NVF
+NE, NE1, TAIL = 32, 20, 23               # tfa_fwd_kernel_x4.h: x4_slot_of<N1, NE1, NE, RB*DT*3-1> with TFA_X4_NE1 = 40, RB = 1
+TILE = 32768
+PPW = 8
+DMA0, DMASTEP = 1, 1
+QBASE = 128
+MFMA = CVT = None
+
+PARSED = {"sa0": "SA0", "sa1": "SA1", "sb0": "SB0", "sb1": "SB1", "l0": "L0", "l1": "L1", "l2": "L2", "l3": "L3",
+          "f0": "F0", "f1": "F1", "f2": "F2", "f3": "F3", "ka": "KA", "kb": "KB"}
+
+
+def parse_block(op, sym):
+    return [f".set {sym}, 0", ".set _tfa_pd, 0", f'.irpc c, "%[{op}]"', ".ifc \\c, :", ".set _tfa_pd, 1", ".endif", ".if _tfa_pd == 0",
+            ".irp d,0,1,2,3,4,5,6,7,8,9", ".ifc \\c, \\d", f".set {sym}, {sym}*10+\\d", ".endif", ".endr", ".endif", ".endr"]
+
+
+def slot_of(n):
+    return 1 + (n * N1 // NE1 if n < NE1 else N1 - 1 + (n - NE1) * TAIL // (NE - NE1))
+
+
+def S(cur, e, n=1):
+    base = ("SA" if cur == "a" else "SB") + ("0" if e < 16 else "1")
+    off = e & 15
+    return f"v[{base}+{off}]" if n == 1 else f"v[{base}+{off}:{base}+{off + n - 1}]"
+
+
+def Sfull(cur, half):
+    return f"%[s{cur}{half}]"
+
+
+def frag(g, n=4, sub=0):
+    b = f"F{g % 4}"
+    return f"%[f{g % 4}]" if (n == 4 and sub == 0) else f"v[{b}+{sub}:{b}+{sub + n - 1}]"
+
+
+def kaddr(ks, buf):
+    """address register and immediate offset base of k-slot ks in K ring buffer buf"""
+    if buf < 2:
+        return ("%[kaddr]" if ks == 0 else f"v[KA+{ks}]"), buf * TILE
+    return f"v[KB+{ks}]", 0
+
+
+def frag_reads(t6, g):
+    """ds_read instructions for fragment g of the tile with phase t6 (0..5); g >= 64 = the first K fragments of the NEXT tile (read in front of the barrier)"""
+    if g >= N1 + N2:
+        return frag_reads((t6 + 1) % 6, g - (N1 + N2))
+    if g < N1:
+        kt, ks = g & 1, g >> 1
+        reg, off = kaddr(ks, (t6 + 1) % 3)               # part 1 reads K(t+1)
+        return [f"ds_read_b128 {frag(g)}, {reg} offset:{off + kt * 16384}"]
+    i = g - N1
+    off = (t6 % 2) * TILE + (i // DT) * 8192 + (i % DT) * 512        # part 2 reads V(t)
+    return [f"ds_read_b64_tr_b16 {frag(g, 2, 0)}, %[va] offset:{off}", f"ds_read_b64_tr_b16 {frag(g, 2, 2)}, %[va] offset:{off + 256}"]
+
+
+def body(t6):
+    par = t6 % 2
+    cur, nxt = ("a", "b") if par == 0 else ("b", "a")
+    o = []
+    a = o.append
+    post = []
+    for g in range(N1 + N2):
+        if g % 2 == 0:
+            rs = frag_reads(t6, g + 2)
+            o.extend(rs)
+            a(f"s_waitcnt lgkmcnt({len(rs)})")
+            post = frag_reads(t6, g + 3)
+        if g < N1:
+            kt, ks = g & 1, g >> 1
+            c = "0" if ks == 0 else Sfull(nxt, kt)
+            a(f"{MFMA} {Sfull(nxt, kt)}, {frag(g)}, a[{QBASE + 4 * ks}:{QBASE + 4 * ks + 3}], {c}")
+        else:
+            i = g - N1
+            ob = 16 * (i % DT)
+            a(f"{MFMA} a[{ob}:{ob + 15}], {frag(g)}, {S(cur, 8 * (i // DT), 4)}, a[{ob}:{ob + 15}]")
+        if g % 2 == 0:
+            o.extend(post)
+        # LDS-DMA: V(t+1) pieces 0..7 -> V buffer par^1, K(t+3) pieces 0..7 -> K ring buffer t % 3, one piece behind each of MFMAs 1..16
+        n = (g - DMA0) // DMASTEP if (g >= DMA0 and (g - DMA0) % DMASTEP == 0) else -1
+        if 0 <= n < PPW:
+            a(f"s_add_u32 m0, %[ldsw], {(3 + (par ^ 1)) * TILE + n * 1024}")
+            a(f"v_add_u32 %[m{nxt}], %[voff], %[vs{n}]")
+            a(f"buffer_load_dwordx4 %[m{nxt}], %[vrs], 0 offen lds")
+        elif PPW <= n < 2 * PPW:
+            a(f"s_add_u32 m0, %[ldsw], {(t6 % 3) * TILE + (n - PPW) * 1024}")
+            a(f"v_add_u32 %[m{nxt}], %[koff], %[ks{n - PPW}]")
+            a(f"buffer_load_dwordx4 %[m{nxt}], %[krs], 0 offen lds")
+        for e in range(NE):
+            if max(slot_of(e) - 2, 0) == g:
+                a(f"v_fma_f32 {S(cur, e)}, {S(cur, e)}, %[sc], -%[mref]")
+        for e in range(NE):
+            if slot_of(e) - 1 == g:
+                a(f"v_exp_f32 {S(cur, e)}, {S(cur, e)}")
+        for e in range(NE):
+            if slot_of(e) == g:
+                a(f"v_add_f32 v[L{e & 3}], v[L{e & 3}], {S(cur, e)}")
+                if e & 1:
+                    s, k = e >> 3, (e & 7) >> 1
+                    a(f"{CVT} {S(cur, 8 * s + k)}, {S(cur, e - 1)}, {S(cur, e)}")
+        # row max of S(t+1), two elements per instruction, from two MFMAs behind the end of its chains (slot N1+2) to the last slot
+        for q in range(16):
+            if N1 + 2 + (q * (N2 - 2)) // 16 == g:
+                if q == 0:
+                    a(f"v_max_f32 %[m{nxt}], {S(nxt, 0)}, {S(nxt, 1)}")
+                else:
+                    a(f"v_max3_f32 %[m{nxt}], %[m{nxt}], {S(nxt, 2 * q)}, {S(nxt, 2 * q + 1)}")
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    a("s_barrier")
+    a("s_add_u32 %[j], %[j], 1")
+    a("s_add_u32 %[koff], %[koff], %[kstr]")
+    a("s_add_u32 %[voff], %[voff], %[vstr]")
+    a("s_cmp_ge_i32 %[j], %[jend]")
+    a(f"v_mul_f32 v[F2], %[sc], %[m{nxt}]")            # (f2 / f3 are dead here; f0 / f1 hold the next tile's first K fragments)
+    a("s_cbranch_scc1 x4_exit%=")
+    a("v_cmp_gt_f32 vcc, v[F2], %[thr]")
+    a("s_cbranch_vccnz x4_exit%=")
+    return o
+
+
+def build(dtype):
+    global MFMA, CVT
+    MFMA = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
+    CVT = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
+    lines = []
+    for op, sym in PARSED.items():
+        lines.extend(parse_block(op, sym))
+    a = lines.append
+    for s in range(1, 16):
+        a(f"v_xor_b32 v[KA+{s}], {s << 5}, %[kaddr]")
+    a("v_add_u32 v[KB+0], 0x10000, %[kaddr]")
+    for s in range(1, 16):
+        a(f"v_add_u32 v[KB+{s}], 0x10000, v[KA+{s}]")
+    a("v_add_f32 %[thr], 0x41000000, %[mref]")
+    a("x4_loop%=:")
+    for t6 in range(6):
+        lines.extend(body(t6))
+    a("s_branch x4_loop%=")
+    a("x4_exit%=:")
+    return lines, len(body(0))
+
+
+def emit(name, lines, n_tile, what):
+    out = [f"#define {name} \\"]
+    for l in lines:
+        esc = l.replace("\\", "\\\\").replace('"', '\\"')
+        out.append(f'  "{esc}\\n\\t" \\')
+    out.append('  ""')
+    out.append(f"#define {name}_INSTR_PER_TILE {n_tile}    // {what}")
+    return out
+
+
+def main():
+    for s in range(4):
+        assert slot_of(8 * s + 7) < N1 + DT * s, "a P slot is packed too late for the PV MFMA that reads it"
+    lb, n = build("bf16")
+    lh, _ = build("f16")
+    out = ["// tfa_fwd_x4_asm_loop.inc — GENERATED by tools/gen_x4_asm_loop.py (do not edit; re-generate).  The steady-state tile loop of fwd_kernel_x4's 256-wide",
+           f"// instantiations (one 32-row block per wave, one wave per SIMD) as hand-scheduled gfx950 assembly: six tile bodies (K ring of three x V pair) of {n}",
+           "// instructions each — 64 MFMA, 128 softmax VALU + 16 row-max + 16 DMA offsets + 2, 96 LDS reads, 16 LDS-DMA, 33 s_waitcnt — where hipcc's schedule is ~590.",
+           "// Layout, rules and the reason: the generator's docstring."]
+    out.extend(emit("TFA_X4_ASM_LOOP", lb, n, "bf16"))
+    out.extend(emit("TFA_X4_ASM_LOOP_F16", lh, n, "fp16"))
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
