@@ -637,24 +637,31 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     // wherever the compiler-scheduled bodies realign after a re-base —, it runs while the next tile exists for the wave, is unmasked, K(j+3) exists and no row
     // outgrew its reference, and returns the first tile it did not process: S(j) in sA / sB by parity, its half-wave row maximum in mA / mB, the first
     // two fragments of K(j+1) in kpre.  The ring offsets are then those of tile j (K(t) lives in ring buffer t % 3).
+    // (its LDS-DMA requests carry the tile's byte offset as their SCALAR offset, which the bounds check does not see: only tiles wholly inside the key sequence)
+    const int nt_full = (p.Nk / BN) < nt ? (p.Nk / BN) : nt;
     constexpr bool ASMX4 = D == 256 && RB == 1 && DVB == 8 && AB == 0 && PF == 2 && PPW == 8 && TFA_X4_USE_ASMLOOP;
     auto asm_loop = [&](int& j) {
       if constexpr (ASMX4) {
         const int lim = fm < nact ? fm : nact;
-        const int jend = (lim - 1 < nt - 3) ? lim - 1 : nt - 3;          // tiles j < jend take the loop
+        const int jend = (lim - 1 < nt_full - 3) ? lim - 1 : nt_full - 3;   // tiles j < jend take the loop
         int koff = (j + 3) * k_tile_stride, voff = (j + 1) * v_tile_stride;
         const unsigned vaddr = lds_base + NKB * TILE_BYTES + (unsigned)v_rd_base;
         const unsigned ldsw = __builtin_amdgcn_readfirstlane(my_piece0);
         float thr;
-        u32x4 f2, f3;
+        u32x4 f2, f3, f4, f5, f6, f7;
         typedef __attribute__((ext_vector_type(16))) unsigned int u32x16;
+#if TFA_X4_ASM_NBUF == 8
+#define TFA_X4_ASM_FRAGS [f2] "=&v"(f2), [f3] "=&v"(f3), [f4] "=&v"(f4), [f5] "=&v"(f5), [f6] "=&v"(f6), [f7] "=&v"(f7)
+#else
+#define TFA_X4_ASM_FRAGS [f2] "=&v"(f2), [f3] "=&v"(f3)
+#endif
         u32x16 ka, kb;
 #define TFA_X4_ASM_STMT(TEXT)                                                                                                                              \
         asm volatile(TEXT                                                                                                                                  \
                      : [sa0] "+v"(sA[0][0]), [sa1] "+v"(sA[0][1]), [sb0] "+v"(sB[0][0]), [sb1] "+v"(sB[0][1]),                                            \
                        [l0] "+v"(l4[0][0]), [l1] "+v"(l4[0][1]), [l2] "+v"(l4[0][2]), [l3] "+v"(l4[0][3]), [ma] "+v"(mA[0]), [mb] "+v"(mB[0]), [j] "+s"(j), \
                        [koff] "+s"(koff), [voff] "+s"(voff), [f0] "+v"(kpre[0]), [f1] "+v"(kpre[1]),                                                      \
-                       [f2] "=&v"(f2), [f3] "=&v"(f3), [ka] "=&v"(ka), [kb] "=&v"(kb), [thr] "=&v"(thr)                                                    \
+                       TFA_X4_ASM_FRAGS, [ka] "=&v"(ka), [kb] "=&v"(kb), [thr] "=&v"(thr)                                                                  \
                      : [mref] "v"(mref[0]), [kaddr] "v"(k_rd_addr), [va] "v"(vaddr),                                                                       \
                        [ks0] "v"(k_src[0]), [ks1] "v"(k_src[1]), [ks2] "v"(k_src[2]), [ks3] "v"(k_src[3]), [ks4] "v"(k_src[4]), [ks5] "v"(k_src[5]),      \
                        [ks6] "v"(k_src[6]), [ks7] "v"(k_src[7]), [vs0] "v"(v_src[0]), [vs1] "v"(v_src[1]), [vs2] "v"(v_src[2]), [vs3] "v"(v_src[3]),      \
@@ -664,6 +671,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         if constexpr (std::is_same<T, __bf16>::value) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP); }
         else { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_F16); }
 #undef TFA_X4_ASM_STMT
+#undef TFA_X4_ASM_FRAGS
+        (void)f4; (void)f5; (void)f6; (void)f7;
         kb0 = (unsigned)(j % 3) * TILE_BYTES;
         kb1 = (unsigned)((j + 1) % 3) * TILE_BYTES;
         kb2 = (unsigned)((j + 2) % 3) * TILE_BYTES;
@@ -672,7 +681,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
 #pragma nounroll
     for (int j = 0; j < nact; j += 2) {
       bool ring_set = false;
-      if (ASMX4 && !(dbg & 1) && (j % 6) == 0 && j + 1 < nact && j + 1 < fm && j + 3 < nt && !trigger(mA)) {
+      if (ASMX4 && !(dbg & 1) && (j % 6) == 0 && j + 1 < nact && j + 1 < fm && j + 3 < nt_full && !trigger(mA)) {
         int jj = j;
         asm_loop(jj);                                  // tiles j .. jj-1 done, jj > j
         ring_set = true;

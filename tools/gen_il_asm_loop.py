@@ -19,7 +19,8 @@ spill 57: the first version).  The kernel is compiled with amdgpu_num_vgpr(96) =
   f0..f3     fragment buffers: K fragments by ds_read_b128, V fragments by two ds_read_b64_tr_b16, read in PAIRS two MFMAs ahead (one s_waitcnt per pair)
   l0..l3     four interleaved partial row sums;  mref (input), thr = mref + 8, tmp;  ma / mb: half-wave row maximum of the even / odd tile a body produced
   ka         K fragment addresses of k-slots 1..7 (kaddr ^ (slot << 5); slot 0 is kaddr itself);  va: V fragment base
-  ks0, ks1, vs0, vs1   lane offsets of this wave's two K and two V LDS-DMA pieces; koff / voff (scalars): byte offset of the tile to request, advanced per tile
+  ks0, ks1, vs0, vs1   lane offsets of this wave's two K and two V LDS-DMA pieces; koff / voff (scalars): byte offset of the tile to request, advanced per
+             tile and handed to the load as its scalar offset (which the bounds check ignores: only tiles wholly inside the key sequence are requested here)
 Single registers of a tuple are reached through assembler symbols (SA0, ... KA) that .irpc blocks at the top parse out of the operand strings.
 """
 import sys
@@ -97,6 +98,15 @@ def body(par, lbl, exact=False, resc=False):
                 cnt = len(rs)
             a(f"s_waitcnt lgkmcnt({cnt})")
             post = frag_reads(g + 3, par) if g + 3 < N1 + N2 else []
+        # LDS-DMA pieces behind the first four MFMAs: V(j+1) -> V buffer par^1, K(j+2) -> K buffer par.  m0 is written in FRONT of the slot's MFMA (which
+        # is the wait state an M0 write needs before the load reads it); the source offset is the piece's lane offset (VGPR) plus the tile's byte offset
+        # as the instruction's SCALAR offset — no VALU add.  The scalar offset takes no part in the descriptor's bounds check: the loop only requests tiles
+        # that lie wholly inside the key sequence (the host side of the statement limits jend), lanes of chunks beyond the head dim stay out of range by themselves
+        gd = g - DMA0
+        if 0 <= gd < 2:
+            a(f"s_add_u32 m0, %[ldsw], {(2 + (par ^ 1)) * TILE + gd * 1024}")
+        elif 2 <= gd < 4:
+            a(f"s_add_u32 m0, %[ldsw], {par * TILE + (gd - 2) * 1024}")
         if g < N1:
             kt, ks = g & 1, g >> 1
             c = "0" if ks == 0 else Sfull(nxt, kt)
@@ -105,20 +115,12 @@ def body(par, lbl, exact=False, resc=False):
             i = g - N1
             ob = 192 + 16 * (i % DT)
             a(f"{MFMA} v[{ob}:{ob + 15}], {frag(g)}, {S(cur, 8 * (i // DT), 4)}, v[{ob}:{ob + 15}]")
-        # LDS-DMA pieces behind the first four MFMAs: V(j+1) -> V buffer par^1, K(j+2) -> K buffer par (m0 write, one VALU as its wait state, the load)
         if g % 2 == 0:
             o.extend(post)
-        # (source offset = the piece's lane offset + the tile's byte offset, kept in a scalar that advances by the tile stride; the address register is a
-        #  scratch one — the row-max register of the tile being produced, dead until part 2 — a load has read it by the time the next instruction issues)
-        gd = g - DMA0
         if 0 <= gd < 2:
-            a(f"s_add_u32 m0, %[ldsw], {(2 + (par ^ 1)) * TILE + gd * 1024}")
-            a(f"v_add_u32 %[m{nxt}], %[voff], %[vs{gd}]")
-            a(f"buffer_load_dwordx4 %[m{nxt}], %[vrs], 0 offen lds")
+            a(f"buffer_load_dwordx4 %[vs{gd}], %[vrs], %[voff] offen lds")
         elif 2 <= gd < 4:
-            a(f"s_add_u32 m0, %[ldsw], {par * TILE + (gd - 2) * 1024}")
-            a(f"v_add_u32 %[m{nxt}], %[koff], %[ks{gd - 2}]")
-            a(f"buffer_load_dwordx4 %[m{nxt}], %[krs], 0 offen lds")
+            a(f"buffer_load_dwordx4 %[ks{gd - 2}], %[krs], %[koff] offen lds")
         if resc and g < N1:                                # the re-basing body: O *= alpha rides behind the QK^T MFMAs, one register quad per MFMA
             for k in range(4):
                 a(f"v_mul_f32 v{192 + 4 * g + k}, v{192 + 4 * g + k}, %[alpha]")
@@ -228,7 +230,7 @@ def main():
     out.append("// tfa_fwd_il_asm_loop.inc — GENERATED by tools/gen_il_asm_loop.py (do not edit; re-generate).  The steady-state tile loop of fwd_kernel_il's")
     out.append("// 128-wide 8-wave instantiations (the headline: bf16, lazy row reference; its fp16 twin) as hand-scheduled gfx950 assembly: ONE basic block of "
                f"{n_tile} instructions per tile")
-    out.append("// (32 MFMA, 128 + 6 VALU, 48 LDS reads, 4 LDS-DMA, 17 s_waitcnt, 12 scalar) where hipcc's schedule of the same work is ~320 in three blocks plus glue;")
+    out.append("// (32 MFMA, 128 + 2 VALU, 48 LDS reads, 4 LDS-DMA, 17 s_waitcnt, 12 scalar) where hipcc's schedule of the same work is ~320 in three blocks plus glue;")
     out.append(f"// and the same for the exact-running-max instantiation (variant 38): {n_xn} instructions per tile, {n_x} in the body that also re-bases O.")
     out.append("// Registers are the COMPILER's choice (generic constraints): the text reaches single registers of a tuple through assembler symbols that the")
     out.append("// leading .irpc blocks parse out of the operand strings (\"v[12:27]\" -> 12).  Rules and layout: the generator's docstring.")

@@ -10,8 +10,8 @@ value), 64 + 21 scalar instructions, 36 s_nop, 12 v_readlane (SGPR spills), one 
   * the K ring (three buffers) and the V pair are unrolled: SIX tile bodies (K(t) in buffer t % 3, V(t) in buffer t % 2, S(t) in sA / sB by t % 2), every LDS
     address an immediate offset on one of two address sets (buffers 0/1: k-slot address + offset; buffer 2 lies beyond the 16-bit offset field: a second set);
   * P is formed in place in the S registers (element e = register e of the S pair; P slot s = registers 8s .. 8s+3), as in the il loop;
-  * fragments travel in pairs (one s_waitcnt per two MFMAs), and the stream does not stop at the tile boundary: the first two K fragments of the next tile are
-    requested behind the last PV MFMAs, in front of the barrier (hipcc's `kpre`), so they are the loop's f0 / f1 on entry and on exit;
+  * fragments travel in groups of four (one s_waitcnt per four MFMAs; eight buffers), and the stream does not stop at the tile boundary: the first K fragments
+    of the next tile are requested behind the last PV MFMAs, in front of the barrier (hipcc's `kpre`): f0 / f1 are `kpre` on entry and on exit;
   * O lives in a[0:127], Q in a[128:191] (tfa_fwd_kernel_x4.h: hand-owned AccVGPRs) and are named literally; everything else is the compiler's choice
     (generic operands; single registers of tuples through assembler symbols parsed from the operand strings, see gen_il_asm_loop.py).
 The loop is entered at a tile j with j % 6 == 0, runs while the next tile exists for the wave, is unmasked, K(j+3) exists and no row outgrew its reference;
@@ -28,9 +28,12 @@ PPW = 8
 DMA0, DMASTEP = 1, 1
 QBASE = 128
 MFMA = CVT = None
+NBUF = 8 if os.environ.get("TFA_GEN_X4_QUAD", "1") == "1" else 4     # fragment buffers: 8 = fragments travel in QUADS (one s_waitcnt per four MFMAs), 4 = pairs
 
 PARSED = {"sa0": "SA0", "sa1": "SA1", "sb0": "SB0", "sb1": "SB1", "l0": "L0", "l1": "L1", "l2": "L2", "l3": "L3",
           "f0": "F0", "f1": "F1", "f2": "F2", "f3": "F3", "ka": "KA", "kb": "KB"}
+if NBUF == 8:
+    PARSED.update({"f4": "F4", "f5": "F5", "f6": "F6", "f7": "F7"})
 
 
 def parse_block(op, sym):
@@ -53,8 +56,8 @@ def Sfull(cur, half):
 
 
 def frag(g, n=4, sub=0):
-    b = f"F{g % 4}"
-    return f"%[f{g % 4}]" if (n == 4 and sub == 0) else f"v[{b}+{sub}:{b}+{sub + n - 1}]"
+    b = f"F{g % NBUF}"
+    return f"%[f{g % NBUF}]" if (n == 4 and sub == 0) else f"v[{b}+{sub}:{b}+{sub + n - 1}]"
 
 
 def kaddr(ks, buf):
@@ -82,13 +85,24 @@ def body(t6):
     cur, nxt = ("a", "b") if par == 0 else ("b", "a")
     o = []
     a = o.append
-    post = []
+    post = {}
+    G = NBUF // 2                                          # fragments per group: the group behind the current one is in flight
     for g in range(N1 + N2):
-        if g % 2 == 0:
-            rs = frag_reads(t6, g + 2)
+        if g % G == 0:
+            # fragment g+G is requested in FRONT of the wait + MFMA g, fragments g+G+1 .. g+2G-1 one behind each of the group's first MFMAs: a read never
+            # lands in the buffer of the MFMA issued just before it, and one s_waitcnt serves G MFMAs
+            rs = frag_reads(t6, g + G)
             o.extend(rs)
             a(f"s_waitcnt lgkmcnt({len(rs)})")
-            post = frag_reads(t6, g + 3)
+            post = {g + k: frag_reads(t6, g + G + 1 + k) for k in range(G - 1)}
+        # LDS-DMA: V(t+1) pieces 0..7 -> V buffer par^1, K(t+3) pieces 0..7 -> K ring buffer t % 3, one piece behind each of MFMAs 1..16.  m0 in FRONT of the
+        # slot's MFMA (the wait state an M0 write needs); source offset = lane offset (VGPR) + the tile's byte offset as the SCALAR offset (no VALU add; the
+        # bounds check ignores it: only tiles wholly inside the key sequence are requested, the statement's jend sees to that)
+        n = (g - DMA0) // DMASTEP if (g >= DMA0 and (g - DMA0) % DMASTEP == 0) else -1
+        if 0 <= n < PPW:
+            a(f"s_add_u32 m0, %[ldsw], {(3 + (par ^ 1)) * TILE + n * 1024}")
+        elif PPW <= n < 2 * PPW:
+            a(f"s_add_u32 m0, %[ldsw], {(t6 % 3) * TILE + (n - PPW) * 1024}")
         if g < N1:
             kt, ks = g & 1, g >> 1
             c = "0" if ks == 0 else Sfull(nxt, kt)
@@ -97,18 +111,11 @@ def body(t6):
             i = g - N1
             ob = 16 * (i % DT)
             a(f"{MFMA} a[{ob}:{ob + 15}], {frag(g)}, {S(cur, 8 * (i // DT), 4)}, a[{ob}:{ob + 15}]")
-        if g % 2 == 0:
-            o.extend(post)
-        # LDS-DMA: V(t+1) pieces 0..7 -> V buffer par^1, K(t+3) pieces 0..7 -> K ring buffer t % 3, one piece behind each of MFMAs 1..16
-        n = (g - DMA0) // DMASTEP if (g >= DMA0 and (g - DMA0) % DMASTEP == 0) else -1
+        o.extend(post.get(g, []))
         if 0 <= n < PPW:
-            a(f"s_add_u32 m0, %[ldsw], {(3 + (par ^ 1)) * TILE + n * 1024}")
-            a(f"v_add_u32 %[m{nxt}], %[voff], %[vs{n}]")
-            a(f"buffer_load_dwordx4 %[m{nxt}], %[vrs], 0 offen lds")
+            a(f"buffer_load_dwordx4 %[vs{n}], %[vrs], %[voff] offen lds")
         elif PPW <= n < 2 * PPW:
-            a(f"s_add_u32 m0, %[ldsw], {(t6 % 3) * TILE + (n - PPW) * 1024}")
-            a(f"v_add_u32 %[m{nxt}], %[koff], %[ks{n - PPW}]")
-            a(f"buffer_load_dwordx4 %[m{nxt}], %[krs], 0 offen lds")
+            a(f"buffer_load_dwordx4 %[ks{n - PPW}], %[krs], %[koff] offen lds")
         for e in range(NE):
             if max(slot_of(e) - 2, 0) == g:
                 a(f"v_fma_f32 {S(cur, e)}, {S(cur, e)}, %[sc], -%[mref]")
@@ -134,9 +141,9 @@ def body(t6):
     a("s_add_u32 %[koff], %[koff], %[kstr]")
     a("s_add_u32 %[voff], %[voff], %[vstr]")
     a("s_cmp_ge_i32 %[j], %[jend]")
-    a(f"v_mul_f32 v[F2], %[sc], %[m{nxt}]")            # (f2 / f3 are dead here; f0 / f1 hold the next tile's first K fragments)
+    a(f"v_mul_f32 v[F{NBUF // 2}], %[sc], %[m{nxt}]")   # (the second half of the fragment buffers is dead here; the first half holds the next tile's first K fragments)
     a("s_cbranch_scc1 x4_exit%=")
-    a("v_cmp_gt_f32 vcc, v[F2], %[thr]")
+    a(f"v_cmp_gt_f32 vcc, v[F{NBUF // 2}], %[thr]")
     a("s_cbranch_vccnz x4_exit%=")
     return o
 
@@ -155,6 +162,8 @@ def build(dtype):
     for s in range(1, 16):
         a(f"v_add_u32 v[KB+{s}], 0x10000, v[KA+{s}]")
     a("v_add_f32 %[thr], 0x41000000, %[mref]")
+    for g in range(2, NBUF // 2):                          # (quads: hipcc's kpre brings fragments 0 and 1 of the first tile; the loop asks for the rest of its first group)
+        lines.extend(frag_reads(0, g))
     a("x4_loop%=:")
     for t6 in range(6):
         lines.extend(body(t6))
@@ -180,8 +189,9 @@ def main():
     lh, _ = build("f16")
     out = ["// tfa_fwd_x4_asm_loop.inc — GENERATED by tools/gen_x4_asm_loop.py (do not edit; re-generate).  The steady-state tile loop of fwd_kernel_x4's 256-wide",
            f"// instantiations (one 32-row block per wave, one wave per SIMD) as hand-scheduled gfx950 assembly: six tile bodies (K ring of three x V pair) of {n}",
-           "// instructions each — 64 MFMA, 128 softmax VALU + 16 row-max + 16 DMA offsets + 2, 96 LDS reads, 16 LDS-DMA, 33 s_waitcnt — where hipcc's schedule is ~590.",
+           "// instructions each — 64 MFMA, 128 softmax VALU + 16 row-max + 2, 96 LDS reads, 16 LDS-DMA, 33 s_waitcnt — where hipcc's schedule is ~590.",
            "// Layout, rules and the reason: the generator's docstring."]
+    out.append(f"#define TFA_X4_ASM_NBUF {NBUF}    // fragment buffers the statement must provide (f0 .. f{NBUF - 1})")
     out.extend(emit("TFA_X4_ASM_LOOP", lb, n, "bf16"))
     out.extend(emit("TFA_X4_ASM_LOOP_F16", lh, n, "fp16"))
     print("\n".join(out))
