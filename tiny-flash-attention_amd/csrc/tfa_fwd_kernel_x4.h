@@ -632,14 +632,14 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     // the wave's last tile and re-bases take the slow path.
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
-    // ---- the hand-scheduled steady state (round 5; tfa_fwd_x4_asm_loop.inc, generated by tools/gen_x4_asm_loop.py): the full 256-wide form only (one 32-row
-    // block per wave, all eight column blocks).  Six tile bodies (K ring of three x V pair): entered at a tile j with j % 6 == 0 — the pass's first tile, or
+    // ---- the hand-scheduled steady state (round 5; tfa_fwd_x4_asm_loop.inc, generated by tools/gen_x4_asm_loop.py): the 256-wide form (one 32-row
+    // block per wave; five to eight valid column blocks: head dims 136..256, one text each).  Six tile bodies (K ring of three x V pair): entered at a tile j with j % 6 == 0 — the pass's first tile, or
     // wherever the compiler-scheduled bodies realign after a re-base —, it runs while the next tile exists for the wave, is unmasked, K(j+3) exists and no row
     // outgrew its reference, and returns the first tile it did not process: S(j) in sA / sB by parity, its half-wave row maximum in mA / mB, the first
     // two fragments of K(j+1) in kpre.  The ring offsets are then those of tile j (K(t) lives in ring buffer t % 3).
     // (its LDS-DMA requests carry the tile's byte offset as their SCALAR offset, which the bounds check does not see: only tiles wholly inside the key sequence)
     const int nt_full = (p.Nk / BN) < nt ? (p.Nk / BN) : nt;
-    constexpr bool ASMX4 = D == 256 && RB == 1 && DVB == 8 && AB == 0 && PF == 2 && PPW == 8 && TFA_X4_USE_ASMLOOP;
+    constexpr bool ASMX4 = D == 256 && RB == 1 && DVB >= 5 && DVB <= 8 && AB == 0 && PF == 2 && PPW == 8 && TFA_X4_USE_ASMLOOP;
     auto asm_loop = [&](int& j) {
       if constexpr (ASMX4) {
         const int lim = fm < nact ? fm : nact;
@@ -668,8 +668,15 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
                        [vs4] "v"(v_src[4]), [vs5] "v"(v_src[5]), [vs6] "v"(v_src[6]), [vs7] "v"(v_src[7]),                                                \
                        [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend) \
                      : TFA_X4_ALLCLOB, "m0", "vcc", "scc", "memory")
-        if constexpr (std::is_same<T, __bf16>::value) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP); }
-        else { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_F16); }
+        constexpr bool BF = std::is_same<T, __bf16>::value;      // one text per (dtype, count of valid 32-column blocks)
+        if constexpr (DVB == 8 && BF) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V8); }
+        else if constexpr (DVB == 8) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V8_F16); }
+        else if constexpr (DVB == 7 && BF) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V7); }
+        else if constexpr (DVB == 7) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V7_F16); }
+        else if constexpr (DVB == 6 && BF) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V6); }
+        else if constexpr (DVB == 6) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V6_F16); }
+        else if constexpr (BF) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V5); }
+        else { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V5_F16); }
 #undef TFA_X4_ASM_STMT
 #undef TFA_X4_ASM_FRAGS
         (void)f4; (void)f5; (void)f6; (void)f7;

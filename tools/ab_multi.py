@@ -9,7 +9,8 @@ from tiny_flash_attention_amd import _lib, ops
 CFG = {"cfg2": (4, 8, 1024, 64, torch.float16, False), "cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096, 128, torch.bfloat16, False),
        "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg4c": (1, 16, 16384, 128, torch.bfloat16, True), "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),
        "n2k": (8, 32, 2048, 128, torch.bfloat16, True), "n1k": (16, 32, 1024, 128, torch.bfloat16, True), "d64": (4, 32, 4096, 64, torch.float16, False),
-       "d64c": (4, 32, 4096, 64, torch.float16, True), "d256c": (4, 8, 4096, 256, torch.bfloat16, True), "d256nc": (4, 8, 4096, 256, torch.bfloat16, False), "d256f16c": (4, 8, 4096, 256, torch.float16, True),
+       "d64c": (4, 32, 4096, 64, torch.float16, True), "d192c": (4, 16, 4096, 192, torch.bfloat16, True), "d160c": (4, 16, 4096, 160, torch.bfloat16, True), "d224nc": (4, 8, 4096, 224, torch.float16, False),
+       "d256c": (4, 8, 4096, 256, torch.bfloat16, True), "d256nc": (4, 8, 4096, 256, torch.bfloat16, False), "d256f16c": (4, 8, 4096, 256, torch.float16, True),
        "d256n16k": (1, 16, 16384, 256, torch.bfloat16, False), "f16c": (4, 16, 4096, 128, torch.float16, True), "f16nc": (4, 16, 4096, 128, torch.float16, False)}
 ap = argparse.ArgumentParser()
 ap.add_argument("libs", nargs="+")

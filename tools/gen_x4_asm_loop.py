@@ -20,9 +20,10 @@ K(j+1) in f0 / f1.  Same arithmetic, same order as the compiler-scheduled body: 
 """
 import os
 
-NKF, NVF, DT = 32, 32, 8                 # K fragments (= S MFMAs), V fragments (= PV MFMAs) per tile, 32-column tiles of O
-N1, N2 = NKF, NVF
-NE, NE1, TAIL = 32, 20, 23               # tfa_fwd_kernel_x4.h: x4_slot_of<N1, NE1, NE, RB*DT*3-1> with TFA_X4_NE1 = 40, RB = 1
+DT = 8                                   # 32-column blocks that hold valid head-dim columns (DVB of tfa_fwd_kernel_x4.h: 5..8; set per text by build())
+N1 = N2 = 4 * DT                         # K fragments (= S MFMAs) and V fragments (= PV MFMAs) per tile
+NE, NE1, TAIL = 32, 20, 3 * DT - 1       # tfa_fwd_kernel_x4.h: x4_slot_of<N1, NE1, NE, RB*DT*3-1> with TFA_X4_NE1 = 40, RB = 1
+DTL = 8                                  # the V tile's LDS layout always counts eight column blocks (the 256-wide image)
 TILE = 32768
 PPW = 8
 DMA0, DMASTEP = 1, 1
@@ -76,7 +77,7 @@ def frag_reads(t6, g):
         reg, off = kaddr(ks, (t6 + 1) % 3)               # part 1 reads K(t+1)
         return [f"ds_read_b128 {frag(g)}, {reg} offset:{off + kt * 16384}"]
     i = g - N1
-    off = (t6 % 2) * TILE + (i // DT) * 8192 + (i % DT) * 512        # part 2 reads V(t)
+    off = (t6 % 2) * TILE + (i // DT) * (2 * DTL * 512) + (i % DT) * 512        # part 2 reads V(t)
     return [f"ds_read_b64_tr_b16 {frag(g, 2, 0)}, %[va] offset:{off}", f"ds_read_b64_tr_b16 {frag(g, 2, 2)}, %[va] offset:{off + 256}"]
 
 
@@ -148,18 +149,24 @@ def body(t6):
     return o
 
 
-def build(dtype):
-    global MFMA, CVT
+def build(dtype, dvb):
+    global MFMA, CVT, DT, N1, N2, TAIL
+    DT = dvb
+    N1 = N2 = 4 * DT
+    TAIL = 3 * DT - 1
+    for s in range(4):
+        assert slot_of(8 * s + 7) < N1 + DT * s, "a P slot is packed too late for the PV MFMA that reads it"
+    assert DMA0 + (2 * PPW - 1) * DMASTEP < N1, "the row-max register serves as nothing else while DMA pieces are in front of it"
     MFMA = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
     CVT = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
     lines = []
     for op, sym in PARSED.items():
         lines.extend(parse_block(op, sym))
     a = lines.append
-    for s in range(1, 16):
+    for s in range(1, 2 * DT):
         a(f"v_xor_b32 v[KA+{s}], {s << 5}, %[kaddr]")
     a("v_add_u32 v[KB+0], 0x10000, %[kaddr]")
-    for s in range(1, 16):
+    for s in range(1, 2 * DT):
         a(f"v_add_u32 v[KB+{s}], 0x10000, v[KA+{s}]")
     a("v_add_f32 %[thr], 0x41000000, %[mref]")
     for g in range(2, NBUF // 2):                          # (quads: hipcc's kpre brings fragments 0 and 1 of the first tile; the loop asks for the rest of its first group)
@@ -183,17 +190,16 @@ def emit(name, lines, n_tile, what):
 
 
 def main():
-    for s in range(4):
-        assert slot_of(8 * s + 7) < N1 + DT * s, "a P slot is packed too late for the PV MFMA that reads it"
-    lb, n = build("bf16")
-    lh, _ = build("f16")
     out = ["// tfa_fwd_x4_asm_loop.inc — GENERATED by tools/gen_x4_asm_loop.py (do not edit; re-generate).  The steady-state tile loop of fwd_kernel_x4's 256-wide",
-           f"// instantiations (one 32-row block per wave, one wave per SIMD) as hand-scheduled gfx950 assembly: six tile bodies (K ring of three x V pair) of {n}",
-           "// instructions each — 64 MFMA, 128 softmax VALU + 16 row-max + 2, 96 LDS reads, 16 LDS-DMA, 33 s_waitcnt — where hipcc's schedule is ~590.",
-           "// Layout, rules and the reason: the generator's docstring."]
-    out.append(f"#define TFA_X4_ASM_NBUF {NBUF}    // fragment buffers the statement must provide (f0 .. f{NBUF - 1})")
-    out.extend(emit("TFA_X4_ASM_LOOP", lb, n, "bf16"))
-    out.extend(emit("TFA_X4_ASM_LOOP_F16", lh, n, "fp16"))
+           "// instantiations (one 32-row block per wave, one wave per SIMD; 5..8 valid 32-column blocks = head dims 136..256) as hand-scheduled gfx950 assembly: six",
+           "// tile bodies (K ring of three x V pair) each; at 8 blocks 346 instructions per tile — 64 MFMA, 128 softmax VALU + 16 row-max + 2, 96 LDS reads, 16 LDS-DMA,",
+           "// 17 s_waitcnt — where hipcc's schedule is ~590.  Layout, rules and the reason: the generator's docstring.",
+           f"#define TFA_X4_ASM_NBUF {NBUF}    // fragment buffers the statement must provide (f0 .. f{NBUF - 1})"]
+    for dvb in (5, 6, 7, 8):
+        lb, n = build("bf16", dvb)
+        lh, _ = build("f16", dvb)
+        out.extend(emit(f"TFA_X4_ASM_LOOP_V{dvb}", lb, n, f"bf16, {dvb} column blocks"))
+        out.extend(emit(f"TFA_X4_ASM_LOOP_V{dvb}_F16", lh, n, f"fp16, {dvb} column blocks"))
     print("\n".join(out))
 
 
