@@ -272,7 +272,7 @@ def workload_text(cfg_name, world, bwd=False, bwd_form="default"):
 
 # the sources that define what the headline kernel executes: a change to any of them makes a recorded HBM-traffic figure stale
 KERNEL_SOURCES = ["tfa_fwd_kernel.h", "tfa_fwd_kernel_dma.h", "tfa_fwd_kernel_il.h", "tfa_fwd_il_regs.h", "tfa_fwd_il_pass_prologue.inc",
-                  "tfa_fwd_il_tile_loop.inc", "tfa_fwd_il_epilogue.inc", "tfa_fwd_inst.inc", "tfa_launch.h", "tfa_api.hip", "Makefile"]
+                  "tfa_fwd_il_tile_loop.inc", "tfa_fwd_il_asm_loop.inc", "tfa_fwd_il_epilogue.inc", "tfa_fwd_inst.inc", "tfa_launch.h", "tfa_api.hip", "Makefile"]
 
 
 def kernel_sources_sha256():

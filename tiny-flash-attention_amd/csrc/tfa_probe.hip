@@ -14,13 +14,16 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-__global__ __launch_bounds__(512, 2) void mfma_stream(const u32x4* src, unsigned chunk_mask, float* sink, int iters) {
-  const unsigned tid = blockIdx.x * 512 + threadIdx.x;
+// (the operand index mask is a CONSTANT — the first 16 MiB of the buffer — on purpose: with a run-time mask hipcc forms 64-bit vector addresses for the sixteen
+//  loads in front of the loop, and that build of the very same loop runs 20 % slower, on zeros as on random data: 1.98 vs 2.47 PF, tools/probe_mfma_variants.hip;
+//  neither the operand registers hipcc picks nor the loop's alignment explain it: tools/probe_mfma_regs.hip, probe_mfma_align.hip, docs/LABLOG.md L-11)
+__global__ __launch_bounds__(512, 2) void mfma_stream(const u32x4* src, float* sink, int iters) {
+  const int tid = blockIdx.x * 512 + threadIdx.x;
   bf16x8 a[8], b[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    a[i] = __builtin_bit_cast(bf16x8, src[(tid * 16 + i) & chunk_mask]);
-    b[i] = __builtin_bit_cast(bf16x8, src[(tid * 16 + 8 + i) & chunk_mask]);
+    a[i] = __builtin_bit_cast(bf16x8, src[(tid * 16 + i) & 0xfffff]);
+    b[i] = __builtin_bit_cast(bf16x8, src[(tid * 16 + 8 + i) & 0xfffff]);
   }
   f32x16 c[4];
 #pragma unroll
@@ -37,14 +40,14 @@ __global__ __launch_bounds__(512, 2) void mfma_stream(const u32x4* src, unsigned
   for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += c[k][r];
-  if (s == 123.456f && sink) sink[tid] = s;      // (never true for finite data: keeps the accumulators alive)
+  if (s == 123.456f) sink[tid] = s;              // (never true for finite data: keeps the accumulators alive)
 }
 }  // namespace
 
 extern "C" int tfa_debug_mfma_ceiling(const void* operands, unsigned long long bytes, double seconds, void* stream, double* tflops) {
-  if (!operands || !tflops || bytes < (1ull << 16) || !(seconds > 0.0) || seconds > 30.0) return TFA_ERR_NULL;
-  unsigned chunks = 1;                             // largest power of two of 16-byte chunks inside the buffer
-  while ((unsigned long long)chunks * 2 * 16 <= bytes && chunks < (1u << 24)) chunks *= 2;
+  if (!operands || !tflops || bytes < (16ull << 20) || !(seconds > 0.0) || seconds > 30.0) return TFA_ERR_NULL;   // the kernel reads the first 16 MiB
+  static float* sink = nullptr;                    // (written only if a lane's sum equals a magic number: never for finite data)
+  if (!sink && hipMalloc(&sink, 1024 * 512 * sizeof(float)) != hipSuccess) return (int)hipGetLastError();
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipGetLastError();
@@ -57,7 +60,7 @@ extern "C" int tfa_debug_mfma_ceiling(const void* operands, unsigned long long b
   do {                                             // groups of `reps` launches between two events; the median of the second half of the groups is reported
     (void)hipGetLastError();
     hipEventRecord(e0, s);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mfma_stream, dim3(grid), dim3(512), 0, s, (const u32x4*)operands, chunks - 1, (float*)nullptr, iters);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mfma_stream, dim3(grid), dim3(512), 0, s, (const u32x4*)operands, sink, iters);
     hipEventRecord(e1, s);
     if (hipEventSynchronize(e1) != hipSuccess) { rc = (int)hipGetLastError(); break; }
     float ms = 0.f;

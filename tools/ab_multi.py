@@ -9,7 +9,8 @@ from tiny_flash_attention_amd import _lib, ops
 CFG = {"cfg2": (4, 8, 1024, 64, torch.float16, False), "cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096, 128, torch.bfloat16, False),
        "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg4c": (1, 16, 16384, 128, torch.bfloat16, True), "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),
        "n2k": (8, 32, 2048, 128, torch.bfloat16, True), "n1k": (16, 32, 1024, 128, torch.bfloat16, True), "d64": (4, 32, 4096, 64, torch.float16, False),
-       "d64c": (4, 32, 4096, 64, torch.float16, True), "d192c": (4, 16, 4096, 192, torch.bfloat16, True), "d160c": (4, 16, 4096, 160, torch.bfloat16, True), "d224nc": (4, 8, 4096, 224, torch.float16, False),
+       "d64c": (4, 32, 4096, 64, torch.float16, True), "decode": (64, 32, 1, 128, torch.bfloat16, True, 8, 8192), "decmha": (64, 32, 1, 128, torch.bfloat16, True, 32, 8192),
+       "d192c": (4, 16, 4096, 192, torch.bfloat16, True), "d160c": (4, 16, 4096, 160, torch.bfloat16, True), "d224nc": (4, 8, 4096, 224, torch.float16, False),
        "d256c": (4, 8, 4096, 256, torch.bfloat16, True), "d256nc": (4, 8, 4096, 256, torch.bfloat16, False), "d256f16c": (4, 8, 4096, 256, torch.float16, True),
        "d256n16k": (1, 16, 16384, 256, torch.bfloat16, False), "f16c": (4, 16, 4096, 128, torch.float16, True), "f16nc": (4, 16, 4096, 128, torch.float16, False)}
 ap = argparse.ArgumentParser()
@@ -32,9 +33,10 @@ for spec in a.libs:
     L.tfa_set_variant.argtypes = [C.c_int]
     entries.append((name, L, int(var) if var else 33))
 for cfg in a.cfgs.split(","):
-    B, H, N, D, dt, causal = CFG[cfg]
-    mk = lambda: (torch.zeros((B, H, N, D), dtype=dt, device=dev) if a.data == "zeros" else torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(dt))
-    q, k, v = mk(), mk(), mk()
+    B, H, N, D, dt, causal = CFG[cfg][:6]
+    Hk, Nk = (CFG[cfg][6], CFG[cfg][7]) if len(CFG[cfg]) > 6 else (H, N)      # (decode-like entries: K/V heads and keys differ from the query side)
+    mk = lambda h=H, n=N: (torch.zeros((B, h, n, D), dtype=dt, device=dev) if a.data == "zeros" else torch.empty((B, h, n, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(dt))
+    q, k, v = mk(), mk(Hk, Nk), mk(Hk, Nk)
     out = torch.empty_like(q); lse = torch.empty((B, H, N), dtype=torch.float32, device=dev)
     p = ops.make_params(q, k, v, out, lse, causal, 1 / math.sqrt(D))
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -63,4 +65,7 @@ for cfg in a.cfgs.split(","):
             torch.cuda.synchronize()
             outs.append((out.clone(), lse.clone()))
         same = "  bits: " + " ".join(f"{e[0]}={'same' if torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) else 'DIFF'}" for e, o in zip(entries, outs))
-    print(f"{cfg:7s}", "  ".join(f"{n}: {sorted(x)[len(x) // 2]:7.1f}" for n, x in res.items()) + same, flush=True)
+    unit = 1.0
+    if cfg.startswith("dec"):                              # decode: report the K/V streaming rate in TB/s instead of TFLOP/s
+        unit = by.value / fl.value
+    print(f"{cfg:7s}", "  ".join(f"{n}: {sorted(x)[len(x) // 2] * unit:7.{3 if unit != 1.0 else 1}f}" for n, x in res.items()) + same + ("  (TB/s)" if unit != 1.0 else ""), flush=True)
