@@ -567,3 +567,24 @@ def test_fp32_tensors_name_the_fix_on_the_16_bit_only_entries():
     l = torch.zeros((1, 1, 8), dtype=torch.float32)
     with pytest.raises(TypeError, match="float16 or bfloat16 only"):
         ops.make_bwd_params(t, t, t, t, l, t, t, t, t, l, False, 1.0)
+
+
+def test_generated_tile_loops_are_in_sync_with_their_generators():
+    """csrc/tfa_fwd_il_asm_loop.inc and tfa_fwd_x4_asm_loop.inc are GENERATED (tools/gen_il_asm_loop.py, gen_x4_asm_loop.py): the committed text must be what
+    the committed generators emit with their default knobs — an edit to either side without the other fails here, before it can reach a GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TFA_GEN_")}
+    for gen, inc in (("gen_il_asm_loop.py", "tfa_fwd_il_asm_loop.inc"), ("gen_x4_asm_loop.py", "tfa_fwd_x4_asm_loop.inc")):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", gen)], stdout=subprocess.PIPE, text=True, check=True, env=env).stdout
+        have = open(os.path.join(root, "tiny-flash-attention_amd", "csrc", inc)).read()
+        assert out == have, f"{inc} is stale: re-run tools/{gen}"
+
+
+def test_library_carries_the_hand_scheduled_loops():
+    """The product library must contain the generated steady-state loops (their asm labels survive as local symbols of the code objects): a build with
+    -DTFA_IL_USE_ASMLOOP=0 / -DTFA_X4_USE_ASMLOOP=0 — the A/B arms — is not what ships."""
+    raw = open(_lib.LIB_PATH, "rb").read()
+    for label in (b"il_loop", b"ix_exit", b"x4_loop"):
+        assert raw.count(label) >= 2, f"no {label.decode()} label in libtfa_hip.so: the hand-scheduled loops are missing from this build"
