@@ -29,6 +29,8 @@ import os
 N1, N2, DT = 16, 16, 4
 NE1 = int(os.environ.get("TFA_GEN_NE1", "21"))             # softmax elements summed / packed behind the QK^T MFMAs (of 32); the rest behind the PV MFMAs
 DMA0 = int(os.environ.get("TFA_GEN_DMA0", "0"))            # first of the four MFMA slots that carry an LDS-DMA piece
+PRE = int(os.environ.get("TFA_GEN_PRE", "0"))              # softmax elements whose scale/subtract AND exp2 are issued in FRONT of the tile's first wait + MFMA (behind the
+                                                           # barrier every wave waits ~100 cycles for its first K fragments: VALU work of the tile's own S fits there)
 EXPD = int(os.environ.get("TFA_GEN_EXPD", "1"))            # an element's exp2 is issued EXPD slots, its scale/subtract 2 * EXPD slots ahead of its sum/pack slot
 TILE = 16384
 MFMA = "v_mfma_f32_32x32x16_bf16"                          # set per dtype by main()
@@ -88,13 +90,20 @@ def body(par, lbl, exact=False, resc=False):
     # never lands in the buffer of the MFMA issued just before it (one MFMA of distance, what hipcc's own schedule keeps) and one s_waitcnt serves two MFMAs
     for g in (0, 1):
         o.extend(frag_reads(g, par))
+    if PRE:
+        o.extend(frag_reads(2, par))                       # (the slot-0 pre-read moves up as well: all three requests are out before the VALU work)
+        for e in range(PRE):
+            a(f"v_fma_f32 {S(cur, e)}, {S(cur, e)}, %[sc], -%[mref]")
+        for e in range(PRE):
+            a(f"v_exp_f32 {S(cur, e)}, {S(cur, e)}")
     post = []
     for g in range(N1 + N2):
         if g % 2 == 0:
             cnt = 0
             if g + 2 < N1 + N2:
                 rs = frag_reads(g + 2, par)
-                o.extend(rs)
+                if not (PRE and g == 0):
+                    o.extend(rs)
                 cnt = len(rs)
             a(f"s_waitcnt lgkmcnt({cnt})")
             post = frag_reads(g + 3, par) if g + 3 < N1 + N2 else []
@@ -125,10 +134,10 @@ def body(par, lbl, exact=False, resc=False):
             for k in range(4):
                 a(f"v_mul_f32 v{192 + 4 * g + k}, v{192 + 4 * g + k}, %[alpha]")
         # this slot's share of tile j's softmax: scale/subtract two slots ahead of an element's own slot, exp2 one ahead, sum + pack in it
-        for e in range(32):
+        for e in range(PRE, 32):
             if max(slot_of_elem(e) - 2 * EXPD, 0) == g:
                 a(f"v_fma_f32 {S(cur, e)}, {S(cur, e)}, %[sc], -%[mref]")
-        for e in range(32):
+        for e in range(PRE, 32):
             if max(slot_of_elem(e) - EXPD, 0) == g:
                 a(f"v_exp_f32 {S(cur, e)}, {S(cur, e)}")
         for e in range(32):
