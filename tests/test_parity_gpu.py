@@ -1099,3 +1099,18 @@ def test_head_dims_that_leave_the_last_column_block_empty(tfa, dev, variant, cau
             assert (lse - torch.logsumexp(s_, dim=-1)).abs().max().item() <= 1e-4
     finally:
         _lib.set_variant(-1)
+
+
+def test_mfma_only_ceiling_probe_returns_a_plausible_rate(tfa, dev):
+    """bench.py quotes `roofline.mfma_only_ceiling_random_data` from tfa_debug_mfma_ceiling (csrc/tfa_probe.hip): it must run on the caller's tensor and stream and
+    land between the rate of the attention kernel and the nominal peak; buffers below 16 MiB are refused."""
+    import ctypes as C
+    from tiny_flash_attention_amd import _lib
+
+    L = _lib.lib()
+    q = torch.empty((16 << 20,), dtype=torch.float32, device=dev).normal_(0.0, 0.5).to(torch.bfloat16)      # 32 MiB of bf16
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t = C.c_double()
+    assert L.tfa_debug_mfma_ceiling(C.c_void_p(q.data_ptr()), C.c_ulonglong(q.numel() * 2), C.c_double(0.5), s, C.byref(t)) == 0
+    assert 1000.0 < t.value < 2600.0, t.value
+    assert L.tfa_debug_mfma_ceiling(C.c_void_p(q.data_ptr()), C.c_ulonglong(1 << 20), C.c_double(0.5), s, C.byref(t)) == -1       # TFA_ERR_NULL: too small
