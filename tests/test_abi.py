@@ -289,14 +289,15 @@ def test_reference_named_extension_modules_import_and_reject_cpu_tensors(module,
 
 def test_variant_selection_is_introspectable_without_gpu():
     # big grids -> the 8-wave issue-interleaved kernel, small grids -> its 4-wave form (128-row blocks, 2 workgroups per CU);
-    # non-causal grids of at most one 128-row block per CU with >= 16 KV tiles -> the key-split form (BASELINE config 2)
+    # grids of at most one 128-row block per CU: causal, or non-causal from 4096 keys on -> the key-split form (BASELINE config 2: il4 since round 5)
     big = _lib.variant_for(4, 32, 32, 4096, 4096, 128, True)
     small = _lib.variant_for(4, 16, 16, 1024, 1024, 64, True, _lib.TFA_F16)
     cfg2 = _lib.variant_for(4, 8, 8, 1024, 1024, 64, False, _lib.TFA_F16)
     assert _lib.variant_name(big).startswith("il8-pair") and _lib.lazy_reference(big)
     assert _lib.variant_name(small).startswith("il4") and _lib.lazy_reference(small)
-    assert _lib.variant_name(cfg2).startswith("il8-ksplit") and _lib.lazy_reference(cfg2)
-    assert _lib.variant_name(_lib.variant_for(4, 8, 8, 512, 512, 64, False, _lib.TFA_F16)).startswith("il4")   # 8 tiles: not worth the merge
+    assert _lib.variant_name(cfg2).startswith("il4") and _lib.lazy_reference(cfg2)
+    assert _lib.variant_name(_lib.variant_for(1, 8, 8, 4096, 4096, 128, False)).startswith("il8-ksplit")
+    assert _lib.variant_name(_lib.variant_for(4, 8, 8, 1024, 1024, 64, True, _lib.TFA_F16)).startswith("il8-ksplit")
     _lib.set_variant(17)
     try:
         assert _lib.variant_for(4, 32, 32, 4096, 4096, 128, True) == 17     # a forced variant is reported as such

@@ -814,16 +814,18 @@ def test_ksplit_small_grids(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal
 
 
 def test_ksplit_dispatch_rule():
-    """Grids of at most one 128-row block per CU: non-causal from 16 KV tiles on, causal from 8.  Non-causal grids with at
+    """Grids of at most one 128-row block per CU: non-causal from 4096 keys on (shorter: the 4-wave kernel, whose hand-scheduled loop overtook
+    the key split in round 5 — profiles/r05_ksplit_retune.txt), causal from 8 KV tiles.  Non-causal grids with at
     least one 256-row block per CU take the 8-wave kernel.  (No GPU needed; kept with the GPU parity tests it belongs to.)"""
     from tiny_flash_attention_amd import _lib
 
     name = lambda *a: _lib.variant_name(_lib.variant_for(*a)).split(" ")[0]
-    assert name(4, 8, 8, 1024, 1024, 64, False) == "il8-ksplit-epi"          # BASELINE config 2
+    assert name(4, 8, 8, 1024, 1024, 64, False) == "il4-pair-epi"            # BASELINE config 2
+    assert name(4, 8, 8, 1024, 1024, 64, True) == "il8-ksplit-epi"
     assert name(1, 8, 8, 4096, 4096, 128, False) == "il8-ksplit-epi"
     assert name(1, 8, 8, 4096, 4096, 128, True) == "il8-ksplit-epi"
     assert name(1, 64, 64, 512, 512, 128, True) == "il8-ksplit-epi"
-    assert name(4, 8, 8, 512, 512, 64, False) == "il4-pair-epi"              # 8 tiles, non-causal: the merge costs more than it returns
+    assert name(1, 16, 16, 2048, 2048, 128, False) == "il4-pair-epi"         # 32 tiles, non-causal: the merge costs more than it returns
     assert name(1, 16, 16, 4096, 4096, 128, True) == "il8-ksplit-pair-epi"   # two 128-row blocks per CU, long sequence: paired key-split
     assert name(1, 32, 32, 2048, 2048, 128, True) == "il4-pair-epi"          # two 128-row blocks per CU, short sequence
     assert name(1, 16, 16, 4096, 4096, 128, False) == "il8-pair-dmaspread-epi"   # one 256-row block per CU, non-causal

@@ -78,12 +78,13 @@ int pick_variant(const tfa_fwd_params* p) {
   const int cus = num_cus();
   // (partial passes — kv_offset / nk_total — reach the kernels as a causal shift only: every rule below applies to them too)
   // Grids of at most one 128-row block per CU: the 4-wave kernel would run one wave per SIMD (causal: paired, on half the CUs) —
-  // split the keys inside the workgroup instead (il8-ksplit: 8 waves on one block, unpaired).  Non-causal it pays from 16 KV
-  // tiles on (BASELINE config 2 +5 %, B1 H16 N2048 +9 %, B1 H8 N4096 +12 %; N=512 -4 %), causal always (B1 H8 N4096 +32 %,
-  // B1 H16 N2048 +32 %, B1 H64 N512 +32 %); with two blocks per CU it is mixed (-20 .. +10 %) and not used
-  // (profiles/r02_ksplit_ab.txt).
+  // split the keys inside the workgroup instead (il8-ksplit: 8 waves on one block, unpaired).  Causal it always pays (B1 H8 N4096 +15 %,
+  // B1 H16 N2048 +19 %, B1 H64 N512 +27 %, B4 H8 N1024 D64 +31 % over il4).  Non-causal the 4-wave kernel with the hand-scheduled tile loop
+  // (round 5: +8..19 % on these grids; the key-split waves see half the tiles each and gain 0..3 %) is ahead up to 2048 keys (BASELINE config 2:
+  // 611 vs 542 TF, B4 H8 N1024 D128 816 vs 762, B1 H16 N2048 955 vs 931) and level at 4096 (1043 vs 1056): key split from 4096 keys on
+  // (profiles/r05_ksplit_retune.txt; rounds 2-4 had it from 1024: profiles/r02_ksplit_ab.txt).
   const bool one_desc = one_descriptor(p);   // (slices of 2 GiB and more: the windowed il4 / il8 instantiations)
-  if (one_desc && blocks128 <= cus && p->Nk >= (p->is_causal ? 512 : 1024)) return tfa::kKSplitVariant;
+  if (one_desc && blocks128 <= cus && p->Nk >= (p->is_causal ? 512 : 4096)) return tfa::kKSplitVariant;
   // causal, up to two 128-row blocks per CU, long sequences: the same kernel with the blocks paired heavy+light (one round of
   // equal workgroups, two waves per SIMD): B1 H16 N4096 +4 %, B1 H8 N8192 +7 %, B1 H4 N16384 +11 % over il4; N=2048: -2..+5 %
   if (one_desc && p->is_causal && blocks128 <= 2 * cus && p->Nk >= 4096) return tfa::kKSplitPairVariant;

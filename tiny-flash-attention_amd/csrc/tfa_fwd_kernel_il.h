@@ -75,16 +75,22 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
 #include "tfa_fwd_il_asm_loop.inc"
 #endif
 // the two asm statements of the hand-scheduled loops (operands = the kernel's locals; the text differs per dtype: tfa_fwd_il_tile_loop.inc picks it)
-#define TFA_IL_ASM_LAZY_STMT(TEXT) \
+#define TFA_IL_ASM_Q8 [q0] "v"(qf[0]), [q1] "v"(qf[1]), [q2] "v"(qf[2]), [q3] "v"(qf[3]), [q4] "v"(qf[4]), [q5] "v"(qf[5]), [q6] "v"(qf[6]), [q7] "v"(qf[7])
+#define TFA_IL_ASM_Q4 [q0] "v"(qf[0]), [q1] "v"(qf[1]), [q2] "v"(qf[2]), [q3] "v"(qf[3])
+#define TFA_IL_ASM_SRC1 [ks0] "v"(k_src[0]), [vs0] "v"(v_src[0])
+#define TFA_IL_ASM_SRC2 [ks0] "v"(k_src[0]), [ks1] "v"(k_src[1]), [vs0] "v"(v_src[0]), [vs1] "v"(v_src[1])
+#define TFA_IL_ASM_SRC4 [ks0] "v"(k_src[0]), [ks1] "v"(k_src[1]), [ks2] "v"(k_src[2]), [ks3] "v"(k_src[3]), [vs0] "v"(v_src[0]), [vs1] "v"(v_src[1]), [vs2] "v"(v_src[2]), [vs3] "v"(v_src[3])
+// (QOPS: the Q fragments of the kernel's width — 8 at 128, 4 at 64; SRCOPS: the lane offsets of the wave's DMA pieces — 1, 2 or 4 per tensor)
+#define TFA_IL_ASM_LAZY_STMT_G(TEXT, QOPS, SRCOPS) \
   asm volatile(TEXT \
   : [sa0] "+v"(sA[0]), [sa1] "+v"(sA[1]), [sb0] "+v"(sB[0]), [sb1] "+v"(sB[1]), \
   [l0] "+v"(l4[0]), [l1] "+v"(l4[1]), [l2] "+v"(l4[2]), [l3] "+v"(l4[3]), [ma] "+v"(mA), [mb] "+v"(mB), [j] "+s"(j), \
   [koff] "+s"(koff), [voff] "+s"(voff), \
   [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2), [f3] "=&v"(f3), [ka] "=&v"(ka), [ka5] "=&v"(ka5), [ka6] "=&v"(ka6), [ka7] "=&v"(ka7), [thr] "=&v"(thr) \
-  : [q0] "v"(qf[0]), [q1] "v"(qf[1]), [q2] "v"(qf[2]), [q3] "v"(qf[3]), [q4] "v"(qf[4]), [q5] "v"(qf[5]), [q6] "v"(qf[6]), [q7] "v"(qf[7]), \
-  [mref] "v"(mref), [kaddr] "v"(k_rd_addr), [va] "v"(vaddr), [ks0] "v"(k_src[0]), [ks1] "v"(k_src[1]), [vs0] "v"(v_src[0]), [vs1] "v"(v_src[1]), \
+  : QOPS, [mref] "v"(mref), [kaddr] "v"(k_rd_addr), [va] "v"(vaddr), SRCOPS, \
   [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend) \
   : TFA_O_CLOB0, TFA_O_CLOB1, TFA_O_CLOB2, TFA_O_CLOB3, "m0", "vcc", "scc", "memory")
+#define TFA_IL_ASM_LAZY_STMT(TEXT) TFA_IL_ASM_LAZY_STMT_G(TEXT, TFA_IL_ASM_Q8, TFA_IL_ASM_SRC2)
 #define TFA_IL_ASM_EXACT_STMT(TEXT) \
   asm volatile(TEXT \
   : [sa0] "+v"(sA[0]), [sa1] "+v"(sA[1]), [sb0] "+v"(sB[0]), [sb1] "+v"(sB[1]), \

@@ -12,7 +12,15 @@ CFG = {"cfg2": (4, 8, 1024, 64, torch.float16, False), "cfg3": (4, 32, 4096, 128
        "d64c": (4, 32, 4096, 64, torch.float16, True), "decode": (64, 32, 1, 128, torch.bfloat16, True, 8, 8192), "decmha": (64, 32, 1, 128, torch.bfloat16, True, 32, 8192),
        "d192c": (4, 16, 4096, 192, torch.bfloat16, True), "d160c": (4, 16, 4096, 160, torch.bfloat16, True), "d224nc": (4, 8, 4096, 224, torch.float16, False),
        "d256c": (4, 8, 4096, 256, torch.bfloat16, True), "d256nc": (4, 8, 4096, 256, torch.bfloat16, False), "d256f16c": (4, 8, 4096, 256, torch.float16, True),
-       "d256n16k": (1, 16, 16384, 256, torch.bfloat16, False), "f16c": (4, 16, 4096, 128, torch.float16, True), "f16nc": (4, 16, 4096, 128, torch.float16, False)}
+       "d256n16k": (1, 16, 16384, 256, torch.bfloat16, False), "d64bfc": (4, 32, 4096, 64, torch.bfloat16, True), "n512": (32, 32, 512, 128, torch.bfloat16, True),
+       "n512d64": (32, 16, 512, 64, torch.float16, False),
+       # grids of at most one / two 128-row blocks per CU (the key-split rules of pick_variant)
+       "k1": (1, 16, 2048, 128, torch.bfloat16, False), "k2": (1, 8, 4096, 128, torch.bfloat16, False), "k3": (4, 8, 1024, 128, torch.bfloat16, False),
+       "k4": (1, 8, 4096, 128, torch.bfloat16, True), "k5": (1, 16, 2048, 128, torch.bfloat16, True), "k6": (1, 64, 512, 128, torch.bfloat16, True),
+       "k7": (2, 8, 2048, 64, torch.float16, False), "k8": (1, 8, 8192, 64, torch.float16, False), "k9": (4, 8, 1024, 64, torch.float16, True),
+       "k10": (1, 32, 1024, 128, torch.bfloat16, False), "k11": (2, 8, 1024, 64, torch.float16, False), "k12": (1, 16, 1024, 128, torch.bfloat16, True),
+       "p1": (1, 16, 4096, 128, torch.bfloat16, True), "p2": (1, 8, 8192, 128, torch.bfloat16, True), "p3": (1, 4, 16384, 128, torch.bfloat16, True),
+       "p4": (2, 16, 4096, 64, torch.float16, True), "p5": (1, 32, 4096, 128, torch.bfloat16, True), "f16c": (4, 16, 4096, 128, torch.float16, True), "f16nc": (4, 16, 4096, 128, torch.float16, False)}
 ap = argparse.ArgumentParser()
 ap.add_argument("libs", nargs="+")
 ap.add_argument("--cfgs", default="cfg3,cfg3nc,cfg4")

@@ -26,13 +26,15 @@ Single registers of a tuple are reached through assembler symbols (SA0, ... KA) 
 import sys
 
 import os
-N1, N2, DT = 16, 16, 4
+N1, N2, DT = 16, 16, 4                                    # QK^T MFMAs, PV MFMAs per tile and 32-column tiles of O: set per text by build() (128 wide: 16, 16, 4; 64 wide: 8, 8, 2)
+DS = 8                                                     # k-slots of 16 columns (Q fragments): D / 16
+PPW = 2                                                    # LDS-DMA pieces per wave per tensor per tile: (64 * D * 2 / 1024) / waves of a key-tile group
 NE1 = int(os.environ.get("TFA_GEN_NE1", "21"))             # softmax elements summed / packed behind the QK^T MFMAs (of 32); the rest behind the PV MFMAs
 DMA0 = int(os.environ.get("TFA_GEN_DMA0", "0"))            # first of the four MFMA slots that carry an LDS-DMA piece
 PRE = int(os.environ.get("TFA_GEN_PRE", "0"))              # softmax elements whose scale/subtract AND exp2 are issued in FRONT of the tile's first wait + MFMA (behind the
                                                            # barrier every wave waits ~100 cycles for its first K fragments: VALU work of the tile's own S fits there)
 EXPD = int(os.environ.get("TFA_GEN_EXPD", "1"))            # an element's exp2 is issued EXPD slots, its scale/subtract 2 * EXPD slots ahead of its sum/pack slot
-TILE = 16384
+TILE = 16384                                               # bytes of a K / V tile in LDS: 64 * D * 2 (set per text)
 MFMA = "v_mfma_f32_32x32x16_bf16"                          # set per dtype by main()
 CVT = "v_cvt_pk_bf16_f32"
 NBUF = int(os.environ.get("TFA_GEN_NBUF", "4"))    # experiment knob: fewer fragment buffers (WRONG results below 4 with this schedule: register-pressure probe only)
@@ -73,10 +75,10 @@ def frag_reads(g, par):
     """ds_read instructions that bring fragment g (0..31) of the tile body into buffer g % 4"""
     if g < N1:
         kt, ks = g & 1, g >> 1
-        off = (par ^ 1) * TILE + kt * 8192
+        off = (par ^ 1) * TILE + kt * (TILE // 2)             # key block kt = rows 32 kt .. of the tile
         return [f"ds_read_b128 {frag(g)}, {KADDR[ks]} offset:{off}"]
     i = g - N1
-    off = (2 + par) * TILE + (i // DT) * 4096 + (i % DT) * 512
+    off = (2 + par) * TILE + (i // DT) * (2 * DT * 512) + (i % DT) * 512
     return [f"ds_read_b64_tr_b16 {frag(g, 2, 0)}, %[va] offset:{off}",
             f"ds_read_b64_tr_b16 {frag(g, 2, 2)}, %[va] offset:{off + 256}"]
 
@@ -112,10 +114,10 @@ def body(par, lbl, exact=False, resc=False):
         # as the instruction's SCALAR offset — no VALU add.  The scalar offset takes no part in the descriptor's bounds check: the loop only requests tiles
         # that lie wholly inside the key sequence (the host side of the statement limits jend), lanes of chunks beyond the head dim stay out of range by themselves
         gd = g - DMA0
-        if 0 <= gd < 2:
+        if 0 <= gd < PPW:
             a(f"s_add_u32 m0, %[ldsw], {(2 + (par ^ 1)) * TILE + gd * 1024}")
-        elif 2 <= gd < 4:
-            a(f"s_add_u32 m0, %[ldsw], {par * TILE + (gd - 2) * 1024}")
+        elif PPW <= gd < 2 * PPW:
+            a(f"s_add_u32 m0, %[ldsw], {par * TILE + (gd - PPW) * 1024}")
         if g < N1:
             kt, ks = g & 1, g >> 1
             c = "0" if ks == 0 else Sfull(nxt, kt)
@@ -126,11 +128,11 @@ def body(par, lbl, exact=False, resc=False):
             a(f"{MFMA} v[{ob}:{ob + 15}], {frag(g)}, {S(cur, 8 * (i // DT), 4)}, v[{ob}:{ob + 15}]")
         if g % 2 == 0:
             o.extend(post)
-        if 0 <= gd < 2:
+        if 0 <= gd < PPW:
             a(f"buffer_load_dwordx4 %[vs{gd}], %[vrs], %[voff] offen lds")
-        elif 2 <= gd < 4:
-            a(f"buffer_load_dwordx4 %[ks{gd - 2}], %[krs], %[koff] offen lds")
-        if resc and g < N1:                                # the re-basing body: O *= alpha rides behind the QK^T MFMAs, one register quad per MFMA
+        elif PPW <= gd < 2 * PPW:
+            a(f"buffer_load_dwordx4 %[ks{gd - PPW}], %[krs], %[koff] offen lds")
+        if resc and g < N1 and N1 * 4 == 16 * DT:          # the re-basing body: O *= alpha rides behind the QK^T MFMAs, one register quad per MFMA
             for k in range(4):
                 a(f"v_mul_f32 v{192 + 4 * g + k}, v{192 + 4 * g + k}, %[alpha]")
         # this slot's share of tile j's softmax: scale/subtract two slots ahead of an element's own slot, exp2 one ahead, sum + pack in it
@@ -146,12 +148,13 @@ def body(par, lbl, exact=False, resc=False):
                 if e & 1:
                     s, k = e >> 3, (e & 7) >> 1
                     a(f"{CVT} {S(cur, 8 * s + k)}, {S(cur, e - 1)}, {S(cur, e)}")
-        if g >= N1:                                        # row max of S(j+1): two elements per slot
-            q = g - N1
-            if q == 0:
-                a(f"v_max_f32 %[m{nxt}], {S(nxt, 0)}, {S(nxt, 1)}")
-            else:
-                a(f"v_max3_f32 %[m{nxt}], %[m{nxt}], {S(nxt, 2 * q)}, {S(nxt, 2 * q + 1)}")
+        if g >= N1:                                        # row max of S(j+1): sixteen pairs of elements over the N2 slots of part 2
+            for q in range(16):
+                if q * N2 // 16 == g - N1:
+                    if q == 0:
+                        a(f"v_max_f32 %[m{nxt}], {S(nxt, 0)}, {S(nxt, 1)}")
+                    else:
+                        a(f"v_max3_f32 %[m{nxt}], %[m{nxt}], {S(nxt, 2 * q)}, {S(nxt, 2 * q + 1)}")
     a("s_waitcnt vmcnt(0)")
     a("s_barrier")
     a("s_add_u32 %[j], %[j], 1")
@@ -195,15 +198,21 @@ def emit(name, lines, n_tile, what):
     return out
 
 
-def build(dtype):
-    """(lines of the lazy-reference loop, lines of the exact-running-max loop, instructions per tile of each body) for one 16-bit type"""
-    global MFMA, CVT
+def build(dtype, d=128, ppw=2):
+    """(lines of the lazy-reference loop, lines of the exact-running-max loop, instructions per tile of each body) for one 16-bit type, kernel width d
+    (128 or 64) and ppw LDS-DMA pieces per wave and tensor (8-wave kernel: 2 / 1; 4-wave and key-split kernels: 4 / 2)"""
+    global MFMA, CVT, N1, N2, DT, DS, TILE, PPW
+    DS, DT, TILE, PPW = d // 16, d // 32, 64 * d * 2, ppw
+    N1, N2 = 2 * DS, 4 * DT
+    for s_ in range(4):
+        assert slot_of_elem(8 * s_ + 7) < N1 + DT * s_, "a P slot is packed too late for the PV MFMA that reads it"
+    assert DMA0 + 2 * PPW <= N1 + N2
     MFMA = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
     CVT = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
     head = []
     for op, sym in PARSED.items():
         head.extend(parse_block(op, sym))
-    for s in range(1, 8):
+    for s in range(1, DS):
         head.append(f"v_xor_b32 {KADDR[s]}, {s << 5}, %[kaddr]")
     # ---- the lazy-reference loop (the headline kernel)
     lines = list(head)
@@ -231,8 +240,6 @@ def build(dtype):
 
 
 def main():
-    for s in range(4):
-        assert slot_of_elem(8 * s + 7) < N1 + DT * s, "a P slot is packed too late for the PV MFMA that reads it"
     lines, xl, n_tile, n_xn, n_x = build("bf16")
     lines_h, xl_h, _, _, _ = build("f16")
     out = []
@@ -247,6 +254,12 @@ def main():
     out.extend(emit("TFA_IL_ASM_LOOP_F16", lines_h, n_tile, "fp16, lazy row reference"))
     out.extend(emit("TFA_IL_ASM_LOOP_EXACT", xl, n_x, "bf16, exact running maximum, the re-basing body"))
     out.extend(emit("TFA_IL_ASM_LOOP_EXACT_F16", xl_h, n_x, "fp16, exact running maximum, the re-basing body"))
+    # the other tile shapes of fwd_kernel_il (lazy row reference only): 128 wide with 4 pieces per wave (the 4-wave and the key-split kernels), 64 wide with
+    # 1 piece (8 waves) or 2 (4-wave / key-split)
+    for d, ppw in ((128, 4), (64, 1), (64, 2)):
+        for dt in ("bf16", "f16"):
+            l_, _, n_, _, _ = build(dt, d, ppw)
+            out.extend(emit(f"TFA_IL_ASM_LOOP_D{d}_P{ppw}" + ("" if dt == "bf16" else "_F16"), l_, n_, f"{dt}, {d} wide, {ppw} DMA pieces per wave and tensor"))
     print("\n".join(out))
 
 
