@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"include/tfa.h declares {n} but libtfa_hip.so does not export it"
     assert sorted(_lib.SYMBOLS) == names
-    assert L.tfa_version() == 108
+    assert L.tfa_version() == 109
 
 
 def _params(B=2, H=4, Hk=4, Nq=128, Nk=128, D=128, dtype=_lib.TFA_BF16, out_dtype=None, scale=0.1, base=0x10000):
@@ -128,7 +128,7 @@ def test_rejects_bad_descriptors():
 
 def test_slices_beyond_2_gib_are_windowed_not_refused():
     # (B,N,H,D) storage, H*D*2 = 128 KiB per row: a head slice of 20000 rows spans 2.6 GB.  The default il kernel takes it
-    # (its windowed instantiation); the split-KV kernel (variant 17) and head dims > 128 (one descriptor per slice) must refuse.
+    # (its windowed instantiation); the split-KV kernel (variant 17: one descriptor per slice) must refuse.
     p = _params(B=1, H=512, Hk=512, Nq=20000, Nk=20000, D=128)
     for name in ("q_stride", "k_stride", "v_stride", "o_stride"):
         a = getattr(p, name)
@@ -139,9 +139,12 @@ def test_slices_beyond_2_gib_are_windowed_not_refused():
         assert plan(p)[0] == -5
     finally:
         _lib.set_variant(-1)
-    p.D = 256
-    assert plan(p)[0] == -5
-    p.D = 128
+    p256 = _params(B=1, H=256, Hk=256, Nq=20000, Nk=20000, D=256)   # the 256-wide kernel has a windowed instantiation too (round 5)
+    for name in ("q_stride", "k_stride", "v_stride", "o_stride"):
+        a = getattr(p256, name)
+        a[0], a[1], a[2] = 20000 * 256 * 256, 256, 256 * 256
+    st, var = plan(p256)[0], _lib.variant_for(1, 256, 256, 20000, 20000, 256, False)
+    assert st == 0 and _lib.variant_name(var).startswith("x4-d256")
     a = p.k_stride; a[2] = 8 * 1024 * 1024                  # 16 MiB per row: even one 64-row tile window exceeds 2 GiB
     assert plan(p)[0] == -5
 

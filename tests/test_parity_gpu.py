@@ -724,7 +724,7 @@ def test_head_slices_beyond_2_gib_in_bnhd_layout(tfa, dev):
     offset reaches.  The default il kernel then runs in its windowed instantiation (per-query-block and per-tile
     descriptors, rsrc_at in tfa_fwd_kernel.h); checked on sampled heads against a device fp32 reference (the rows near the
     END of the sequence are the ones whose offsets exceed 2 GiB).  tfa_fwd_splitkv takes its one-launch-per-chunk route through the
-    same windowed kernels; head dims > 128 still need slices below 2 GiB."""
+    same windowed kernels."""
     from tiny_flash_attention_amd import _lib, ops
 
     B, N, H, D = 1, 17408, 512, 128                       # row stride H*D*2 = 128 KiB -> slice = 2.28e9 bytes
@@ -757,17 +757,55 @@ def test_head_slices_beyond_2_gib_in_bnhd_layout(tfa, dev):
         assert (l2[0, h] - lse[0, h]).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("variant", _avail([30, 32]))
+@pytest.mark.parametrize("causal", [True, False])
+def test_head_slices_beyond_2_gib_at_head_dim_256(tfa, dev, causal):
+    """The same for the 256-wide kernel (round 5: rounds 1-4 answered TFA_ERR_STRIDE above 128): (B,N,H,D) storage, D = 256, 128 heads — 64 KiB per
+    row, 2.2 GiB per head slice.  Sampled heads against a device fp32 reference at both ends of the sequence; Nq != Nk and a ragged last tile."""
+    from tiny_flash_attention_amd import ops
+
+    B, Nq, Nk, H, D = 1, 33000, 34001, 128, 256
+    assert (Nq - 1) * H * D * 2 > 2 ** 31
+    g = torch.Generator(device=dev).manual_seed(93)
+    mk = lambda n: torch.empty((B, n, H, D), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(torch.bfloat16)
+    q, k, v = mk(Nq), mk(Nk), mk(Nk)
+    sc = 1.0 / math.sqrt(D)
+    out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout="bnhd")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out[:, -512:].float()).all())
+    shift = Nk - Nq
+    for h in (0, 77, 127):
+        qh, kh, vh = (t[0, :, h].float() for t in (q, k, v))
+        for rows in (slice(Nq - 300, Nq), slice(0, 200)):                 # the tail (offsets beyond 2 GiB) and the head of the sequence
+            s_ = (qh[rows] @ kh.t()) * sc
+            if causal:
+                qi = torch.arange(Nq, device=dev)[rows]
+                s_.masked_fill_(torch.arange(Nk, device=dev)[None, :] > qi[:, None] + shift, float("-inf"))
+            ref = torch.softmax(s_, dim=-1) @ vh
+            assert (out[0, rows, h].float() - ref).abs().max().item() <= 1e-2
+            assert (lse[0, h, rows] - torch.logsumexp(s_, dim=-1)).abs().max().item() <= 1e-4
+    if causal:      # split-KV on such slices: one launch of the windowed 256-wide kernel per key chunk, fp32 partials, the same merge
+        o2, l2 = ops.flash_attn_fwd_splitkv(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), True, sc, splits=2)
+        torch.cuda.synchronize()
+        for h in (0, 77, 127):
+            assert (o2[0, h].float() - out[0, :, h].float()).abs().max().item() <= 4e-3
+            assert (l2[0, h] - lse[0, h]).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("variant", _avail([30, 32, 34]))
 @pytest.mark.parametrize("causal", [False, True])
 def test_windowed_instantiation_returns_the_same_bits(tfa, dev, variant, causal):
     """The windowed instantiation (launched for slices >= 2 GiB) forced onto ordinary inputs through the debug flag:
-    bit-identical output and LSE, ragged lengths, Nq != Nk, GQA, strided (B,N,H,D) storage and a padded head dim included."""
+    bit-identical output and LSE, ragged lengths, Nq != Nk, GQA, strided (B,N,H,D) storage and a padded head dim included.
+    Variant 34 = the 256-wide kernel (head dims 136..256 run it whatever is forced; round 5: its windowed instantiation)."""
     from tiny_flash_attention_amd import _lib, ops
 
     g = torch.Generator(device=dev).manual_seed(92)
     cases = [(2, 4, 4, 1024, 1024, 128, "bhnd"), (1, 4, 2, 777, 1333, 128, "bnhd"), (2, 2, 2, 1500, 1500, 64, "bnhd"),
              (1, 2, 2, 640, 640, 96, "bhnd")]
-    _lib.set_variant(variant)
+    if variant == 34:
+        cases = [(2, 4, 4, 1024, 1024, 256, "bhnd"), (1, 4, 2, 777, 1333, 192, "bnhd"), (2, 2, 2, 1500, 1500, 256, "bnhd"),
+                 (1, 2, 2, 640, 640, 160, "bhnd"), (1, 2, 1, 200, 3000, 136, "bnhd")]
+    _lib.set_variant(-1 if variant == 34 else variant)
     try:
         for B, H, Hk, Nq, Nk, D, layout in cases:
             shp = (lambda n, h: (B, h, n, D)) if layout == "bhnd" else (lambda n, h: (B, n, h, D))

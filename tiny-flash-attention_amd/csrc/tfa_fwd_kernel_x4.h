@@ -31,6 +31,8 @@ namespace tfa {
 
 constexpr int VF_X4 = 1 << 22;            // this kernel
 constexpr int VF_X4_EPI = 1 << 23;        // 16-bit O leaves through a separate LDS region as whole rows (16-byte stores)
+constexpr int VF_X4_WINDOWED = 1 << 24;    // (b,h) slices of 2 GiB and more: K/V through one descriptor per tile, Q / O through one per query block (rsrc_at), as the il
+                                           // kernels' VF_IL_WINDOWED; the compiler-scheduled tile bodies only (the hand-scheduled loop adds the tile offset as the DMA's scalar offset)
 constexpr int VF_X4_EPI_INPLACE = 1 << 30; // ... through the (idle) tile buffers instead: D = 256, whose five 32 KiB buffers fill the LDS.  A barrier
                                           // behind the epilogue when another pass follows (its first DMA pieces land in other waves' slices)
 
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   constexpr int NKB = 3;                           // K ring
   constexpr bool PAIR = CAUSAL && (VF & VF_PAIR);
   constexpr bool EPI_IN = (VF & VF_X4_EPI_INPLACE) != 0;
+  constexpr bool WIN = (VF & VF_X4_WINDOWED) != 0;
   constexpr bool EPI = (VF & VF_X4_EPI) != 0 || EPI_IN;
   static_assert(!EPI_IN || 4 * RB * 32 * D * 2 <= (NKB + 2) * 64 * D * 2, "in-place epilogue slices inside the tile buffers");
   static_assert(PPW >= 1 && PPW * NW == PIECES, "tile does not split into whole DMA pieces per wave");
@@ -205,9 +208,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   const T* qbase = reinterpret_cast<const T*>(p.q) + b * p.qs_b + h * p.qs_h;
   const T* kbase = reinterpret_cast<const T*>(p.k) + b * p.ks_b + hk * p.ks_h;
   const T* vbase = reinterpret_cast<const T*>(p.v) + b * p.vs_b + hk * p.vs_h;
-  auto q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, (unsigned)p.q_bytes, 0x00020000);
-  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (unsigned)p.k_bytes, 0x00020000);
-  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (unsigned)p.v_bytes, 0x00020000);
+  // one descriptor per slice (the host guarantees < 2 GiB) — or, WINDOWED, K/V: one per tile, Q / O: one per query block, offsets relative to it
+  auto k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, WIN ? 0u : (unsigned)p.k_bytes, 0x00020000);
+  auto v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, WIN ? 0u : (unsigned)p.v_bytes, 0x00020000);
+  auto slice_rsrc = [&](const void* base, unsigned long long bytes, unsigned long long off) {
+    if constexpr (WIN) return rsrc_at(base, bytes, off);
+    else return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)bytes, 0x00020000);
+  };
 
   // per-lane DMA source offsets of this wave's pieces (tile 0); the K swizzle and the V sub-tile order are applied to the
   // SOURCE address, the LDS destination of piece pc is pc * 1024 + lane * 16 (tfa_fwd_kernel_dma.h)
@@ -232,8 +239,18 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
   const int k_tile_stride = BN * (int)p.ks_n * 2;
   const int v_tile_stride = BN * (int)p.vs_n * 2;
   const unsigned my_piece0 = lds_base + wave * PPW * 1024;
-  auto dma_k1 = [&](int t, unsigned kboff, int i) { lds_dma16_m0(k_rs, my_piece0 + kboff + i * 1024, k_src[i] + t * k_tile_stride); };
-  auto dma_v1 = [&](int t, int vbuf, int i) { lds_dma16_m0(v_rs, my_piece0 + (NKB + vbuf) * TILE_BYTES + i * 1024, v_src[i] + t * v_tile_stride); };
+  // piece i of K tile t into the ring buffer at kboff.  WINDOWED: the tile's own descriptor; `off` = the lane's source offset inside the tile, or TFA_OOB
+  auto dma_k_win = [&](int t, unsigned kboff, int i, int off) {
+    lds_dma16_m0_fresh(rsrc_at(kbase, p.k_bytes, (unsigned long long)(unsigned)t * (unsigned)k_tile_stride), my_piece0 + kboff + i * 1024, off);
+  };
+  auto dma_k1 = [&](int t, unsigned kboff, int i) {
+    if constexpr (WIN) dma_k_win(t, kboff, i, k_src[i]);
+    else lds_dma16_m0(k_rs, my_piece0 + kboff + i * 1024, k_src[i] + t * k_tile_stride);
+  };
+  auto dma_v1 = [&](int t, int vbuf, int i) {
+    if constexpr (WIN) lds_dma16_m0_fresh(rsrc_at(vbase, p.v_bytes, (unsigned long long)(unsigned)t * (unsigned)v_tile_stride), my_piece0 + (NKB + vbuf) * TILE_BYTES + i * 1024, v_src[i]);
+    else lds_dma16_m0(v_rs, my_piece0 + (NKB + vbuf) * TILE_BYTES + i * 1024, v_src[i] + t * v_tile_stride);
+  };
   auto dma_k = [&](int t, unsigned kboff) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) dma_k1(t, kboff, i);
@@ -294,9 +311,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     if (nt > 2) dma_k(2, 2 * TILE_BYTES);
     {
       u32x4 qv[RB][DS];
+      auto q_rs = slice_rsrc(qbase, p.q_bytes, (unsigned long long)(unsigned)q0 * (unsigned long long)p.qs_n * 2);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        const int qoff = (wave_row0 + rb * 32 + qi) * (int)p.qs_n * 2 + hi * 16;
+        const int qoff = (wave_row0 - (WIN ? q0 : 0) + rb * 32 + qi) * (int)p.qs_n * 2 + hi * 16;
 #pragma unroll
         for (int s = 0; s < DS; ++s) qv[rb][s] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, (2 * s + hi) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB, 0, 0);
       }
@@ -516,8 +534,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
           constexpr int n = (g - TFA_X4_DMA0) / TFA_X4_DMASTEP;
           if constexpr (n < PPW) dma_v1(j + 1, PAR ^ 1, n);
 #if defined(TFA_X4_BRANCHY_K)
-          else { if (issue_k) lds_dma16_m0(k_rs, my_piece0 + kb0 + (n - PPW) * 1024, k_src[n - PPW] + (j + 3) * k_tile_stride); }
+          else { if (issue_k) dma_k1(j + 3, kb0, n - PPW); }
 #else
+          else if constexpr (WIN) dma_k_win(j + 3, kb0, n - PPW, issue_k ? k_src[n - PPW] : (int)TFA_OOB);
           else lds_dma16_m0(k_rs, my_piece0 + kb0 + (n - PPW) * 1024, issue_k ? k_src[n - PPW] + k_tile_off : (int)TFA_OOB);
 #endif
         }
@@ -639,7 +658,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
     // two fragments of K(j+1) in kpre.  The ring offsets are then those of tile j (K(t) lives in ring buffer t % 3).
     // (its LDS-DMA requests carry the tile's byte offset as their SCALAR offset, which the bounds check does not see: only tiles wholly inside the key sequence)
     const int nt_full = (p.Nk / BN) < nt ? (p.Nk / BN) : nt;
-    constexpr bool ASMX4 = D == 256 && RB == 1 && DVB >= 5 && DVB <= 8 && AB == 0 && PF == 2 && PPW == 8 && TFA_X4_USE_ASMLOOP;
+    constexpr bool ASMX4 = D == 256 && RB == 1 && DVB >= 5 && DVB <= 8 && AB == 0 && PF == 2 && PPW == 8 && !WIN && TFA_X4_USE_ASMLOOP;
     auto asm_loop = [&](int& j) {
       if constexpr (ASMX4) {
         const int lim = fm < nact ? fm : nact;
@@ -727,8 +746,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
       }
       if constexpr (F32OUT) {
         float* obase = reinterpret_cast<float*>(p.o) + b * p.os_b + h * p.os_h;
-        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
-        const int ooff = my_row * (int)p.os_n * 4 + hi * 16;
+        auto o_rs = slice_rsrc(obase, p.o_bytes, (unsigned long long)(unsigned)q0 * (unsigned long long)p.os_n * 4);
+        const int ooff = (my_row - (WIN ? q0 : 0)) * (int)p.os_n * 4 + hi * 16;
         static_for<0, DT * 4>([&](auto c_c) {
           constexpr int c = decltype(c_c)::value, R = (rb * DT + c / 4) * 16 + (c % 4) * 4;
           f32x4 v4 = {x4_o_read<R>() * inv, x4_o_read<R + 1>() * inv, x4_o_read<R + 2>() * inv, x4_o_read<R + 3>() * inv};
@@ -739,7 +758,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
         // lane, 32 different rows per instruction.  Instead the wave transposes each 32 x D block through its own slice
         // of the epilogue region (16-byte chunk index XOR row, as for K) and writes whole rows: 1 KiB contiguous per store.
         T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
-        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
+        auto o_rs = slice_rsrc(obase, p.o_bytes, (unsigned long long)(unsigned)q0 * (unsigned long long)p.os_n * 2);
         typedef __attribute__((ext_vector_type(4))) T t4;
         int qix = qi, lanex = lane;                  // (through an empty asm: none of the addresses below may be hoisted out of the pass loop)
         asm volatile("" : "+v"(qix), "+v"(lanex));
@@ -758,13 +777,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
           const int r = i * RPI + lanex / CH, cpos = lanex % CH;
           const int c = cpos ^ ((CH >= 16) ? (r & 15) : (r & 7));
           u32x4 v = *reinterpret_cast<const u32x4*>(ow + r * (D * 2) + (cpos << 4));
-          __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 + rb * 32 + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, 2);   // nt: see tfa_fwd_kernel_il.h
+          __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, c * 8 < p.dv ? (wave_row0 - (WIN ? q0 : 0) + rb * 32 + r) * (int)p.os_n * 2 + (c << 4) : (int)TFA_OOB, 0, 2);   // nt: see tfa_fwd_kernel_il.h
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by this wave's next epilogue only
       } else {
         T* obase = reinterpret_cast<T*>(p.o) + b * p.os_b + h * p.os_h;
-        auto o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, (unsigned)p.o_bytes, 0x00020000);
-        const int ooff = my_row * (int)p.os_n * 2 + hi * 8;
+        auto o_rs = slice_rsrc(obase, p.o_bytes, (unsigned long long)(unsigned)q0 * (unsigned long long)p.os_n * 2);
+        const int ooff = (my_row - (WIN ? q0 : 0)) * (int)p.os_n * 2 + hi * 8;
         typedef __attribute__((ext_vector_type(4))) T t4;
         static_for<0, DT * 4>([&](auto c_c) {
           constexpr int c = decltype(c_c)::value, R = (rb * DT + c / 4) * 16 + (c % 4) * 4;

@@ -190,7 +190,7 @@ static inline bool supports_padded_d(int variant) {
 
 // kernels that address a (b,h) slice through windowed descriptors (rsrc_at): the slice may exceed 2 GiB
 static inline bool windowed_slices(int variant) {
-  return variant == kDefaultVariant || variant == kSmallGridVariant;   // the dispatched il kernels have a windowed instantiation
+  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kX4D256Variant;   // the dispatched il kernels and the 256-wide kernel have a windowed instantiation
 }
 
 static inline int block_m_of(int variant) {
