@@ -454,7 +454,8 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     nt_total += nt;
 
     const int wave_row0 = q0 + wrow * 32;
-    const int my_row = wave_row0 + qi;
+    // (the 4-wave and key-split instantiations re-derive the lane's row here: `qi` kept live from the kernel's first instructions cost their first prologue a spill)
+    const int my_row = wave_row0 + ((NW == 4 || KSPLIT) ? (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 31u) : qi);
     const int pos_lo = rmod > 0 ? 0 : wave_row0, pos_hi = rmod > 0 ? rmod - 1 : wave_row0 + 31;   // positions of the wave's rows: [pos_lo, pos_hi]
     const int my_pos = rmod > 0 ? my_row % rmod : my_row;
     const int last_g = CAUSAL ? ((pos_hi + shift) >= 0 ? (pos_hi + shift) / BN : -1) : (ntg - 1);   // last tile of the head the wave's rows see
