@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 109 /* 0.1.9: (b,h) slices of 2 GiB and more at head dims above 128 (windowed instantiation of the 256-wide forward kernel; TFA_ERR_STRIDE before), tfa_debug_mfma_ceiling; 0.1.8: TFA_FWD_EXACT_MAX runs the il8 kernel's exact-max instantiation (variant 38) on grids that fill the chip; 0.1.7: tfa_bwd computes delta inside its dQ launch (tfa_debug_bwd_split bit 3 restores the separate launch), tfa_debug_set_trace is served by traced twins of the main kernels; 0.1.6: + fp32 q,k,v (TFA_F32 input: the correctness path behind the reference's fp32 fixtures), variant numbers are ids (tfa_variant_available), tfa_bwd_workspace_bytes is 0 wherever the workspace would be ignored; 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
+#define TFA_VERSION 109 /* 0.1.9: (b,h) slices of 2 GiB and more at head dims above 128 (windowed instantiations of the 256-wide forward and backward kernels; TFA_ERR_STRIDE before), tfa_debug_mfma_ceiling; 0.1.8: TFA_FWD_EXACT_MAX runs the il8 kernel's exact-max instantiation (variant 38) on grids that fill the chip; 0.1.7: tfa_bwd computes delta inside its dQ launch (tfa_debug_bwd_split bit 3 restores the separate launch), tfa_debug_set_trace is served by traced twins of the main kernels; 0.1.6: + fp32 q,k,v (TFA_F32 input: the correctness path behind the reference's fp32 fixtures), variant numbers are ids (tfa_variant_available), tfa_bwd_workspace_bytes is 0 wherever the workspace would be ignored; 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
 
 /* element types */
 enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1,
@@ -71,9 +71,8 @@ enum tfa_status {
                                * TFA_FWD_EXACT_MAX: not a multiple of 8 in [8,128] */
   TFA_ERR_SHAPE = -4,         /* B,H,Hk,Nq,Nk <= 0 or H % Hk != 0 */
   TFA_ERR_STRIDE = -5,        /* a stride is negative, not 16-byte aligned, rows overlap, or 768 rows of a (b,h) slice span 2 GiB
-                               * (tfa_fwd switches to per-block / per-tile descriptor windows when a slice is larger, ~6 % slower — at
-                               * every head dim since 0.1.9 —, and so does tfa_bwd for D <= 128; tfa_fwd_splitkv then runs one windowed
-                               * launch per key chunk; tfa_bwd with D > 128 uses one descriptor per slice: the whole slice must stay below 2 GiB) */
+                               * (tfa_fwd and tfa_bwd switch to per-block / per-tile descriptor windows when a slice is larger, ~6 % / ~3 %
+                               * slower — at every head dim since 0.1.9; tfa_fwd_splitkv then runs one windowed launch per key chunk) */
   TFA_ERR_ALIGN = -6,         /* a base pointer is not 16-byte aligned */
   TFA_ERR_VARIANT = -7,       /* unknown kernel variant */
   TFA_ERR_SCALE = -8          /* softmax_scale is not finite or is <= 0 */

@@ -399,15 +399,17 @@ def test_bwd_descriptor_validation_without_gpu():
     assert L.tfa_bwd_plan(C.byref(p)) == -5
     p = _bwd_params(); p.dout = 0x10008
     assert L.tfa_bwd_plan(C.byref(p)) == -6
-    # (b,h) slices of 2 GiB and more ((B,N,H,D) storage, 128 KiB per row, 20000 rows): the windowed instantiations take them for head
-    # dims up to 128; the 256-wide launches keep one descriptor per slice and refuse
+    # (b,h) slices of 2 GiB and more ((B,N,H,D) storage, 128 KiB per row, 20000 rows): the windowed instantiations take them
     def strided(D):
         p = _bwd_params(B=1, H=512, Hk=512, Nq=20000, Nk=20000, D=D)
         for name in ("q_stride", "k_stride", "v_stride", "o_stride", "do_stride", "dq_stride", "dk_stride", "dv_stride"):
             a = getattr(p, name); a[0], a[1], a[2] = 20000 * 512 * D, D, 512 * D
         return p
     assert L.tfa_bwd_plan(C.byref(strided(128))) == 0
-    assert L.tfa_bwd_plan(C.byref(strided(256))) == -5
+    assert L.tfa_bwd_plan(C.byref(strided(256))) == 0           # (round 5: the 256-wide launches have windowed instantiations too)
+    huge = strided(256)
+    huge.k_stride[2] = 8 * 1024 * 1024                          # 16 MiB per row: a 768-row window exceeds 2 GiB
+    assert L.tfa_bwd_plan(C.byref(huge)) == -5
     # work model: 2.5 x the forward's flops (5 GEMMs), halved when causal
     f, b = C.c_double(), C.c_double()
     p = _bwd_params(B=4, H=32, Hk=32, Nq=4096, Nk=4096, D=128)

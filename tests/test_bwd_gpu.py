@@ -292,6 +292,9 @@ def test_bwd_headline_shape_properties(tfa, dev):
     (torch.bfloat16, 2, 4, 2, 700, 900, 128, True, "bhnd"),
     (torch.float16, 1, 4, 4, 513, 513, 64, True, "bnhd"),
     (torch.bfloat16, 1, 6, 2, 320, 200, 96, False, "bnhd"),
+    (torch.bfloat16, 1, 4, 2, 600, 777, 256, True, "bnhd"),      # the 256-wide kernel: its three launches each have a windowed instantiation (round 5)
+    (torch.float16, 2, 2, 2, 400, 400, 192, False, "bhnd"),
+    (torch.bfloat16, 1, 2, 1, 257, 1000, 136, True, "bnhd"),
 ])
 def test_bwd_windowed_instantiations_return_the_same_bits(tfa, oracle, dev, dtype, B, H, Hk, Nq, Nk, D, causal, layout):
     """The windowed instantiations of the dQ launch and of the fused dK/dV launch (what slices of 2 GiB and more get) forced onto
@@ -314,6 +317,38 @@ def test_bwd_windowed_instantiations_return_the_same_bits(tfa, oracle, dev, dtyp
         _lib.debug_bwd_split(0)
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)
+
+
+def test_bwd_head_slices_beyond_2_gib_at_head_dim_256(tfa, dev):
+    """The same at head dim 256 (round 5: TFA_ERR_STRIDE before): (B,N,H,D) storage, 256 heads of 256 — 128 KiB per row, 2.2 GiB per head slice; the
+    256-wide kernel's three launches in their windowed instantiations, two heads against fp32 autograd on the device."""
+    from tiny_flash_attention_amd import ops
+
+    B, N, H, D = 1, 17000, 256, 256
+    assert (N - 1) * H * D * 2 > 2 ** 31
+    g = torch.Generator(device=dev).manual_seed(94)
+    mk = lambda: torch.empty((B, N, H, D), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(torch.bfloat16)
+    q, k, v, dout = mk(), mk(), mk(), mk()
+    sc = 1.0 / math.sqrt(D)
+    out, lse = ops.flash_attn_fwd(q, k, v, True, sc, layout="bnhd")
+    dq, dk, dv = ops.flash_attn_bwd(q, k, v, out, lse, dout, True, sc, layout="bnhd")
+    torch.cuda.synchronize()
+    del out
+    idx = torch.arange(N, device=dev)
+    for h in (0, 255):
+        qh, kh, vh = (t[0, :, h].float().detach().requires_grad_(True) for t in (q, k, v))
+        s_ = (qh @ kh.t()) * sc
+        s_ = s_.masked_fill(idx[None, :] > idx[:, None], float("-inf"))
+        o = torch.softmax(s_, dim=-1) @ vh
+        o.backward(dout[0, :, h].float())
+        for name, got, want in (("dq", dq[0, :, h], qh.grad), ("dk", dk[0, :, h], kh.grad), ("dv", dv[0, :, h], vh.grad)):
+            gt = got.float()
+            assert bool(torch.isfinite(gt).all()), name
+            d = (gt - want).abs()
+            bar = 2e-2 * want.abs().max().item() + 1e-3
+            assert d.max().item() <= bar, f"head {h} {name}: max|d| {d.max().item():.3e} > {bar:.3e}"
+            assert d[-640:].max().item() <= bar                              # the tail of the sequence: offsets beyond 2 GiB
+        del s_, o, qh, kh, vh
 
 
 def test_bwd_head_slices_beyond_2_gib_in_bnhd_layout(tfa, dev):

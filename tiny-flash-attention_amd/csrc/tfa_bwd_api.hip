@@ -103,8 +103,8 @@ int run_bwd(const tfa_bwd_params* p, void* stream, bool dry, long long* ws_need 
   tfa::BArgs a;
   memset(&a, 0, sizeof(a));
   // slices of 2 GiB and more (long (B,N,H,D) tensors): the windowed instantiations of the dQ launch and of the fused dK/dV launch —
-  // head dims up to 128, not with the two-launch debug form
-  const bool can_big = p->D <= 128 && !(g_bwd_split & 1);
+  // not with the two-launch debug form at head dims up to 128 (its dK / dV launches have no windowed instantiation; the 256-wide kernel has one for each of its three launches)
+  const bool can_big = p->D > 128 || !(g_bwd_split & 1);
   int big = (g_bwd_split & 2) ? 1 : 0;        // tests: the windowed instantiations on a small problem
   int* bigp = can_big ? &big : nullptr;
   if (!fill(&a.q, p->q, p->q_stride, p->Nq, p->D, esz, bigp)) return TFA_ERR_STRIDE;

@@ -98,15 +98,15 @@ template <int D> static __device__ __forceinline__ int u_swz(int row) {
 // 128 resident-fragment + 128 accumulator registers in the dK launch —, unified images; hipcc places the accumulators in AGPRs)
 // BIG: (b,h) slices of 2 GiB and more (long (B,N,H,D) tensors): every descriptor is a WINDOW (rsrc_at) — one per streamed tile, one
 // over the workgroup's resident rows, one over its gradient rows — and the 32-bit offsets are window-relative.  Its own instantiation
-// (a fresh descriptor per tile costs scalar work and wait states), launched only when a slice needs it; dQ mode only (the fused
-// dK/dV launch has its own).
+// (a fresh descriptor per tile costs scalar work and wait states), launched only when a slice needs it; dQ mode only at head dims up to 128 (the fused
+// dK/dV launch has its own), all three modes of the 256-wide kernel (round 5).
 // DVB: 32-wide column blocks that can hold valid head-dim columns — ceil(head dim / 32): 5..8 in the 256-wide kernels, 3 (head dims
 // up to 96) in the 128-wide dQ kernel, 1 (up to 32) in the 64-wide one.  The LDS images
 // and every address stay 256 wide (the columns beyond the head dim are the descriptors' zeros); the GEMM loops run over the valid
 // blocks only: at D = 160 / 192 / 224 that is 5/8, 6/8, 7/8 of the matrix work, fragment registers and LDS reads.
 template <typename T, int D, int MODE, bool CAUSAL, bool F32OUT, bool UNI = false, int NW = 8, bool BIG = false, int DVB = D / 32>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BArgs p) {
-  static_assert(!BIG || MODE == BWD_DQ, "BIG: the dQ launch");
+  static_assert(!BIG || MODE == BWD_DQ || D > 128, "BIG: the dQ launch; at head dims above 128 (no fused dK/dV launch) all three");
   using E = Elem<T>;
   using X8 = typename E::x8;
   constexpr int BM = NW * 32;                      // resident rows per workgroup
