@@ -22,6 +22,11 @@ spill 57: the first version).  The kernel is compiled with amdgpu_num_vgpr(96) =
   ks0, ks1, vs0, vs1   lane offsets of this wave's two K and two V LDS-DMA pieces; koff / voff (scalars): byte offset of the tile to request, advanced per
              tile and handed to the load as its scalar offset (which the bounds check ignores: only tiles wholly inside the key sequence are requested here)
 Single registers of a tuple are reached through assembler symbols (SA0, ... KA) that .irpc blocks at the top parse out of the operand strings.
+
+Shapes (second half of round 5): build(dtype, d, ppw) writes the text for a kernel width d (128: eight k-slots, four O column tiles, 16 KiB tiles; 64: four,
+two, 8 KiB) and ppw LDS-DMA pieces per wave and tensor (tile bytes / 1 KiB / waves of a key-tile group: il8 2 / 1, il4 and the key-split kernels 4 / 2).  The
+file carries TFA_IL_ASM_LOOP[_F16] (128 x 2, the headline), _EXACT[_F16] (128 x 2, exact running maximum), _D128_P4, _D64_P1, _D64_P2 (+ _F16); q4..q7,
+ka5..ka7 and the higher ks / vs operands exist only in the shapes that have them (tfa_fwd_kernel_il.h: TFA_IL_ASM_LAZY_STMT_G).
 """
 import sys
 
