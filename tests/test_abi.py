@@ -592,5 +592,14 @@ def test_library_carries_the_hand_scheduled_loops():
     """The product library must contain the generated steady-state loops (their asm labels survive as local symbols of the code objects): a build with
     -DTFA_IL_USE_ASMLOOP=0 / -DTFA_X4_USE_ASMLOOP=0 — the A/B arms — is not what ships."""
     raw = open(_lib.LIB_PATH, "rb").read()
-    for label in (b"il_loop", b"ix_exit", b"x4_loop"):
-        assert raw.count(label) >= 2, f"no {label.decode()} label in libtfa_hip.so: the hand-scheduled loops are missing from this build"
+    # one label per kernel that carries a loop: the lazy-reference loop in 8 units x (il8, il4, key split, key split paired) x two output types, the exact loop in
+    # the 128-wide causal / non-causal units of both types, the 256-wide loop in 32 units
+    for label, least in ((b"il_loop", 64), (b"ix_exit", 8), (b"x4_loop", 32)):
+        assert raw.count(label) >= least, f"{raw.count(label)} {label.decode()} labels in libtfa_hip.so, expected {least}: hand-scheduled loops are missing from this build"
+    # ... and the windowed instantiations that (b,h) slices of 2 GiB and more run (round 5: the 256-wide forward kernel, VF | VF_X4_WINDOWED, and the 256-wide
+    # backward kernel with BIG = true in all three modes)
+    import re
+    x4win = set(re.findall(rb"_ZN3tfa13fwd_kernel_x4I[0-9A-Za-z_]*Li1090519044E[0-9A-Za-z_]*", raw))
+    assert len(x4win) == 8, sorted(x4win)                      # 2 dtypes x causal x output type
+    bwdwin = set(re.findall(rb"_ZN3tfa10bwd_kernelI\w+?Li256ELi[012]ELb[01]ELb[01]ELb1ELi4ELb1ELi8E\w*", raw))
+    assert len(bwdwin) == 24, len(bwdwin)                      # 2 dtypes x 3 modes x causal x gradient type
