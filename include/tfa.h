@@ -310,7 +310,9 @@ int tfa_debug_decode(int B, int H, int Hk, int nwork, int id, int* out);
 /* Measurement aid (bench.py): the rate in TFLOP/s that a stream of nothing but v_mfma_f32_32x32x16_bf16 sustains on this GPU with operand values
  * taken from the first 16 MiB of `operands` (device memory, `bytes` >= 16 MiB of bf16 data — bench.py passes its q tensor), launched on `stream` for about `seconds`
  * (<= 30); synchronises the stream.  On the reference's normal(0, 0.5) inputs the board's power cap holds that stream to ~0.68 of the nominal
- * 2.5 PFLOP/s and boxes differ by +-5 %: the figure belongs next to `roofline.frac`, measured in the same run, not hard-coded. */
+ * 2.5 PFLOP/s and boxes differ by +-5 %: the figure belongs next to `roofline.frac`, measured in the same run, not hard-coded.
+ * It SYNCHRONISES `stream` between its groups of launches and allocates / frees device memory: it cannot be called inside a stream capture.
+ * *tflops is 0 on every error return (bad sizes: TFA_ERR_SHAPE; no timed group completed: hipErrorNotReady). */
 int tfa_debug_mfma_ceiling(const void* operands, unsigned long long bytes, double seconds, void* stream, double* tflops);
 
 /* Algorithmic work of *p: flops = 4*B*H*Nq*Nk*D (x1/2 when causal, the reference's

@@ -159,6 +159,9 @@ def _og_worker(rank, world, port, shape, causal, chunks, q_out):
         for lo, hi, view in res.slab(r):                                               # ... and the views: same values, and they ARE the gather buffers
             ok = ok and bool(torch.equal(view, want[lo:hi])) and any(view.data_ptr() == og.parts[c][r].data_ptr() for c in range(og.nchunks))
         ok = ok and all(bool(torch.equal(res.batch(r, b), want[b])) for b in range(Bl))
+        # tensor-style indexing (callers written against the assembled tensor): a rank's rows, one row, a slice across ranks — same values; an int is a view
+        ok = ok and bool(torch.equal(res[r * Bl:(r + 1) * Bl], want)) and bool(torch.equal(res[r * Bl], want[0])) and res[r * Bl].data_ptr() == res.batch(r, 0).data_ptr()
+    ok = ok and tuple(res.shape) == (world * Bl, H, N, D) and bool(torch.equal(res[0:world * Bl], og.full)) and bool(torch.equal(res[-1], og.full[-1]))
     ok = ok and [row for row, _ in res] == list(range(world * Bl))
     q_out.put((rank, ok, "og"))
     dist.barrier()

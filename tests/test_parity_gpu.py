@@ -1153,4 +1153,7 @@ def test_mfma_only_ceiling_probe_returns_a_plausible_rate(tfa, dev):
     t = C.c_double()
     assert L.tfa_debug_mfma_ceiling(C.c_void_p(q.data_ptr()), C.c_ulonglong(q.numel() * 2), C.c_double(0.5), s, C.byref(t)) == 0
     assert 1000.0 < t.value < 2600.0, t.value
-    assert L.tfa_debug_mfma_ceiling(C.c_void_p(q.data_ptr()), C.c_ulonglong(1 << 20), C.c_double(0.5), s, C.byref(t)) == -1       # TFA_ERR_NULL: too small
+    # a size / duration error is TFA_ERR_SHAPE (-4), not TFA_ERR_NULL, and leaves 0 in *tflops; a NULL pointer is TFA_ERR_NULL
+    assert L.tfa_debug_mfma_ceiling(C.c_void_p(q.data_ptr()), C.c_ulonglong(1 << 20), C.c_double(0.5), s, C.byref(t)) == -4 and t.value == 0.0
+    assert L.tfa_debug_mfma_ceiling(C.c_void_p(q.data_ptr()), C.c_ulonglong(q.numel() * 2), C.c_double(0.0), s, C.byref(t)) == -4
+    assert L.tfa_debug_mfma_ceiling(None, C.c_ulonglong(q.numel() * 2), C.c_double(0.5), s, C.byref(t)) == -1

@@ -81,14 +81,19 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
 #define TFA_IL_ASM_SRC2 [ks0] "v"(k_src[0]), [ks1] "v"(k_src[1]), [vs0] "v"(v_src[0]), [vs1] "v"(v_src[1])
 #define TFA_IL_ASM_SRC4 [ks0] "v"(k_src[0]), [ks1] "v"(k_src[1]), [ks2] "v"(k_src[2]), [ks3] "v"(k_src[3]), [vs0] "v"(v_src[0]), [vs1] "v"(v_src[1]), [vs2] "v"(v_src[2]), [vs3] "v"(v_src[3])
 // (QOPS: the Q fragments of the kernel's width — 8 at 128, 4 at 64; SRCOPS: the lane offsets of the wave's DMA pieces — 1, 2 or 4 per tensor)
+// Round 6: the lazy-reference statement also carries the bodies BEHIND the loop (dispatch + pinned / masked / last-tile body per parity, tools/gen_il_asm_loop.py:
+// tail_blocks): [nact] the wave's tile count, [fmx] its first masked tile (-1: tails off — leave at jend as before), [nt] the block's tile count, [slim] the scalar part of the
+// lanes' mask limit for tile fmx (apply_mask's: the wave's first row + the causal shift - the tile's first key), [ts] a scratch scalar.  One statement, one register assignment: as statements of their own the tails made hipcc move
+// whole accumulator tuples through scratch between them (480 bytes per lane)
 #define TFA_IL_ASM_LAZY_STMT_G(TEXT, QOPS, SRCOPS) \
   asm volatile(TEXT \
   : [sa0] "+v"(sA[0]), [sa1] "+v"(sA[1]), [sb0] "+v"(sB[0]), [sb1] "+v"(sB[1]), \
   [l0] "+v"(l4[0]), [l1] "+v"(l4[1]), [l2] "+v"(l4[2]), [l3] "+v"(l4[3]), [ma] "+v"(mA), [mb] "+v"(mB), [j] "+s"(j), \
-  [koff] "+s"(koff), [voff] "+s"(voff), \
+  [koff] "+s"(koff), [voff] "+s"(voff), [ts] "=&s"(ts), \
   [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2), [f3] "=&v"(f3), [ka] "=&v"(ka), [ka5] "=&v"(ka5), [ka6] "=&v"(ka6), [ka7] "=&v"(ka7), [thr] "=&v"(thr) \
   : QOPS, [mref] "v"(mref), [kaddr] "v"(k_rd_addr), [va] "v"(vaddr), SRCOPS, \
-  [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend) \
+  [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend), \
+  [nact] "s"(nact_s), [fmx] "s"(fmx), [nt] "s"(nt_s), [slim] "s"(slim) \
   : TFA_O_CLOB0, TFA_O_CLOB1, TFA_O_CLOB2, TFA_O_CLOB3, "m0", "vcc", "scc", "memory")
 #define TFA_IL_ASM_LAZY_STMT(TEXT) TFA_IL_ASM_LAZY_STMT_G(TEXT, TFA_IL_ASM_Q8, TFA_IL_ASM_SRC2)
 #define TFA_IL_ASM_EXACT_STMT(TEXT) \
@@ -101,6 +106,9 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
   [kaddr] "v"(k_rd_addr), [va] "v"(vaddr), [ks0] "v"(k_src[0]), [ks1] "v"(k_src[1]), [vs0] "v"(v_src[0]), [vs1] "v"(v_src[1]), \
   [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend) \
   : TFA_O_CLOB0, TFA_O_CLOB1, TFA_O_CLOB2, TFA_O_CLOB3, "m0", "vcc", "scc", "memory")
+#if !defined(TFA_IL_USE_ASMTAIL)
+#define TFA_IL_USE_ASMTAIL 1     // 0: the compiler-scheduled bodies outside the loop (the A/B arm of the round-6 tail bodies)
+#endif
 #if !defined(TFA_IL_USE_ASMLOOP)
 #define TFA_IL_USE_ASMLOOP 1     // 0: the compiler-scheduled body everywhere (the A/B arm of the hand-scheduled steady state, tools/r5_arm.sh)
 #endif

@@ -45,12 +45,17 @@ __global__ __launch_bounds__(512, 2) void mfma_stream(const u32x4* src, float* s
 }  // namespace
 
 extern "C" int tfa_debug_mfma_ceiling(const void* operands, unsigned long long bytes, double seconds, void* stream, double* tflops) {
-  if (!operands || !tflops || bytes < (16ull << 20) || !(seconds > 0.0) || seconds > 30.0) return TFA_ERR_NULL;   // the kernel reads the first 16 MiB
-  static float* sink = nullptr;                    // (written only if a lane's sum equals a magic number: never for finite data)
-  if (!sink && hipMalloc(&sink, 1024 * 512 * sizeof(float)) != hipSuccess) return (int)hipGetLastError();
+  if (!operands || !tflops) return TFA_ERR_NULL;
+  *tflops = 0.0;
+  if (bytes < (16ull << 20) || !(seconds > 0.0) || seconds > 30.0) return TFA_ERR_SHAPE;   // the kernel reads the first 16 MiB
+  // (the sink is written only if a lane's sum equals a magic number — never for finite data.  One per call, on the device that is current NOW: a static
+  //  pointer would belong to whichever device and thread came first.  The call synchronises the stream, so it cannot be part of a stream capture: tfa.h)
+  float* sink = nullptr;
+  if (hipMalloc(&sink, 1024 * 512 * sizeof(float)) != hipSuccess) return (int)hipGetLastError();
   hipStream_t s = (hipStream_t)stream;
-  hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipGetLastError();
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess) { const int rc = (int)hipGetLastError(); (void)hipFree(sink); return rc; }
+  if (hipEventCreate(&e1) != hipSuccess) { const int rc = (int)hipGetLastError(); (void)hipEventDestroy(e0); (void)hipFree(sink); return rc; }
   const int grid = 1024, iters = 4000, reps = 2;   // ~40 ms per group: host round trips between groups stay below 0.3 %
   const double flops = (double)grid * 8 * iters * 32 * 32768.0 * reps;
   double rates[512];
@@ -59,17 +64,20 @@ extern "C" int tfa_debug_mfma_ceiling(const void* operands, unsigned long long b
   int rc = TFA_OK;
   do {                                             // groups of `reps` launches between two events; the median of the second half of the groups is reported
     (void)hipGetLastError();
-    hipEventRecord(e0, s);
+    (void)hipEventRecord(e0, s);
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mfma_stream, dim3(grid), dim3(512), 0, s, (const u32x4*)operands, sink, iters);
-    hipEventRecord(e1, s);
+    (void)hipEventRecord(e1, s);
     if (hipEventSynchronize(e1) != hipSuccess) { rc = (int)hipGetLastError(); break; }
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     if (ms > 0.f && nr < 512) rates[nr++] = flops / (ms * 1e-3) / 1e12;
   } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds);
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  if (rc == TFA_OK && nr > 0) {                    // (the first half of the groups is the clock settling on this stream: the firmware's power loop swings +-15 % per group)
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  if (rc != TFA_OK) return rc;
+  if (nr == 0) return (int)hipErrorNotReady;       // not one timed group: nothing to report (*tflops stays 0; positive = a HIP error code, tfa.h)
+  {                                                // (the first half of the groups is the clock settling on this stream: the firmware's power loop swings +-15 % per group)
     const int lo = nr / 2, n = nr - lo;
     for (int i = lo + 1; i < nr; ++i) {            // insertion sort of the second half
       const double x = rates[i];

@@ -157,6 +157,31 @@ class Gathered:
             for b in range(self.B):
                 yield r * self.B + b, self.batch(r, b)
 
+    @property
+    def shape(self):
+        """shape of the assembled tensor: (world*B, H, N, D)"""
+        return (self.world * self.B,) + tuple(self.parts[0].shape[2:])
+
+    def __getitem__(self, idx):
+        """Tensor-style indexing over the global batch rows, for callers written against the assembled tensor (`full[r*B:(r+1)*B]`): an int or a
+        contiguous slice that stays inside one rank's rows of one chunk is a zero-copy VIEW of the gather buffer; anything else indexes `.cat()`
+        (a copy of the whole output)."""
+        n = len(self)
+        if isinstance(idx, int):
+            if not -n <= idx < n:
+                raise IndexError(idx)
+            r, b = divmod(idx % n, self.B)
+            return self.batch(r, b)
+        if isinstance(idx, slice):
+            start, stop, step = idx.indices(n)
+            if step == 1 and start < stop:
+                (r0, b0), (r1, b1) = divmod(start, self.B), divmod(stop - 1, self.B)
+                if r0 == r1:
+                    for c, (lo, hi) in enumerate(self.bounds):
+                        if lo <= b0 and b1 < hi:
+                            return self.parts[c][r0, b0 - lo:b1 - lo + 1]
+        return self.cat()[idx]
+
     def cat(self):
         """the assembled (world*B, H, N, D) tensor — a COPY when there is more than one chunk"""
         full = self.parts[0] if len(self.parts) == 1 else torch.cat(self.parts, dim=1)
@@ -211,7 +236,9 @@ class OverlappedGather:
         """The gathered output of all ranks after join(), WITHOUT copying it: a `Gathered` view over the per-chunk buffers the collectives wrote
         (`parts[c]`, shape (world, rows of chunk c, H, N, D)).  `res.slab(r)` / `res.batch(r, b)` / iteration hand out views; `res.cat()` — and
         the `full` property — assemble the (world*B, H, N, D) tensor, which is a copy of the whole output (2.1 GB per call at BASELINE config 5 on
-        8 ranks) and is there for callers that really need one contiguous tensor."""
+        8 ranks) and is there for callers that really need one contiguous tensor.  `Gathered` also answers `shape`, `len()` and tensor-style
+        `res[i]` / `res[a:b]` over the global batch rows (views where the rows lie in one buffer, else an index into `.cat()`), so that callers written
+        against the assembled tensor of the earlier versions keep working."""
         self.join()
         return Gathered(self.parts, self.bounds, self.world, self.q.shape[0])
 

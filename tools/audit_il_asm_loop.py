@@ -11,11 +11,28 @@ s_branch) in every kernel that has one and checks, per tile body:
   4. an LDS read never lands in a fragment buffer whose MFMA was issued fewer than 1 MFMA ago (the distance hipcc's own schedule keeps);
   5. the block is ONE basic block per tile (no branch targets inside), and reports its instruction mix."""
 import collections
+import os
 import re
+import shutil
 import subprocess
 import sys
 
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+def find_objdump():
+    """llvm-objdump of the toolchain that built the object: $TFA_OBJDUMP, else next to $HIPCC / under $ROCM_PATH, else /opt/rocm, else PATH"""
+    cands = [os.environ.get("TFA_OBJDUMP", "")]
+    hipcc = os.environ.get("HIPCC", "")
+    if hipcc:
+        root = os.path.dirname(os.path.dirname(os.path.realpath(shutil.which(hipcc) or hipcc)))
+        cands += [os.path.join(root, "lib", "llvm", "bin", "llvm-objdump"), os.path.join(root, "llvm", "bin", "llvm-objdump")]
+    for root in (os.environ.get("ROCM_PATH", ""), "/opt/rocm"):
+        if root:
+            cands.append(os.path.join(root, "lib", "llvm", "bin", "llvm-objdump"))
+    cands.append(shutil.which("llvm-objdump") or "")
+    for c in cands:
+        if c and os.path.isfile(c) and os.access(c, os.X_OK):
+            return c
+    sys.exit("audit_il_asm_loop.py: no llvm-objdump found (looked at: " + ", ".join(c for c in cands if c) + "); set TFA_OBJDUMP or ROCM_PATH")
 
 
 def regs(tok):
@@ -41,10 +58,85 @@ def parse(line):
     return op, ops
 
 
+def check(loop, report_from=0):
+    """findings (strings) of the linear scan of `loop`; only findings at instruction index >= report_from are returned (a sequence checked twice in a
+    row — body n, then body n + 1 = the loop's back edge — reports the second copy only)"""
+    out = []
+
+    def say(idx, msg):
+        if idx >= report_from:
+            out.append(msg)
+
+    pending = collections.deque()          # LDS reads in flight: destination registers, in issue order
+    inflight = set()
+    mfma_written = {}                      # reg -> index of the MFMA that last wrote it
+    valu_written = {}                      # reg -> index of the VALU instruction that last wrote it
+    mfma_read_ab = {}                      # reg -> count of MFMAs issued when an MFMA last read it as A/B
+    n_mfma = 0
+    for idx, (op, ops) in enumerate(loop):
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", " ".join(ops))
+            if m:
+                keep = int(m.group(1))
+                while len(pending) > keep:
+                    for r in pending.popleft():
+                        inflight.discard(r)
+            continue
+        if op.startswith("s_") and "branch" in op and not op.startswith("s_cbranch_scc1") and False:
+            pass
+        if op in ("s_barrier",) or op.startswith("s_"):
+            continue
+        dst = regs(ops[0]) if ops else []
+        srcs = [r for o in ops[1:] for r in regs(o)]
+        if op.startswith("ds_read"):
+            addr = regs(ops[1])
+            for r in addr:
+                if r in inflight:
+                    say(idx, f"   [1] {op} address v{r} still in flight (#{idx})")
+            for r in dst:
+                if r in mfma_read_ab and n_mfma - mfma_read_ab[r] < 1:
+                    say(idx, f"   [4] {op} lands in v{r}, read by the MFMA issued just before (#{idx})")
+            pending.append(dst)
+            inflight.update(dst)
+            continue
+        if op.startswith("buffer_load"):
+            srcs = regs(ops[0])
+            dst = []
+        for r in srcs + (dst if not op.startswith("v_mfma") else []):
+            if r in inflight:
+                say(idx, f"   [1] {op} touches v{r} while its LDS read is in flight (#{idx})")
+        if op.startswith("v_mfma"):
+            for r in srcs:
+                if r in valu_written and idx - valu_written[r] < 3:      # >= 2 instructions strictly between
+                    say(idx, f"   [2] {op} reads v{r} written by a VALU instruction {idx - valu_written[r] - 1} instructions earlier (#{idx})")
+            for r in regs(ops[1]) + regs(ops[2]):
+                mfma_read_ab[r] = n_mfma + 1
+            n_mfma += 1
+            for r in dst:
+                mfma_written[r] = idx
+            continue
+        for r in srcs + dst:
+            if r in mfma_written:
+                ws = sum(8 if loop[k][0].startswith("v_mfma") else 1 for k in range(mfma_written[r] + 1, idx))
+                if ws < 12:
+                    say(idx, f"   [3] {op} touches v{r}, an MFMA result only {ws} wait states old (#{idx})")
+        if op.startswith("v_") and not op.startswith("v_cmp"):
+            for r in dst:
+                valu_written[r] = idx
+
+    return out
+
+
 def main():
+    allow_missing = "--allow-missing" in sys.argv          # (an A/B build with -DTFA_IL_USE_ASMLOOP=0 / -DTFA_X4_USE_ASMLOOP=0 has no loop to audit: the Makefile says so)
+    if allow_missing:
+        sys.argv.remove("--allow-missing")
     obj = sys.argv[1]
     pat = sys.argv[2] if len(sys.argv) > 2 else "fwd_kernel_"
-    txt = subprocess.run([OBJDUMP, "-d", obj], stdout=subprocess.PIPE, text=True).stdout
+    r = subprocess.run([find_objdump(), "-d", obj], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0 or not r.stdout:
+        sys.exit(f"audit_il_asm_loop.py: llvm-objdump failed on {obj} (exit {r.returncode}): {r.stderr.strip()[:300]}")
+    txt = r.stdout
     kernels, cur = collections.OrderedDict(), None
     for line in txt.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
@@ -82,69 +174,32 @@ def main():
             mix[k] += 1
         print(f"{name[:100]}\n   loop: {len(loop)} instructions, {n_tiles} tiles -> {len(loop) / n_tiles:.0f} per tile: " +
               "  ".join(f"{k} {v / n_tiles:.1f}" for k, v in sorted(mix.items())))
-        pending = collections.deque()          # LDS reads in flight: destination registers, in issue order
-        inflight = set()
-        mfma_written = {}                      # reg -> index of the MFMA that last wrote it
-        valu_written = {}                      # reg -> index of the VALU instruction that last wrote it
-        mfma_read_ab = {}                      # reg -> count of MFMAs issued when an MFMA last read it as A/B
-        n_mfma = 0
-        for idx, (op, ops) in enumerate(loop):
-            if op == "s_waitcnt":
-                m = re.search(r"lgkmcnt\((\d+)\)", " ".join(ops))
-                if m:
-                    keep = int(m.group(1))
-                    while len(pending) > keep:
-                        for r in pending.popleft():
-                            inflight.discard(r)
-                continue
-            if op.startswith("s_") and "branch" in op and not op.startswith("s_cbranch_scc1") and False:
-                pass
-            if op in ("s_barrier",) or op.startswith("s_"):
-                continue
-            dst = regs(ops[0]) if ops else []
-            srcs = [r for o in ops[1:] for r in regs(o)]
-            if op.startswith("ds_read"):
-                addr = regs(ops[1])
-                for r in addr:
-                    if r in inflight:
-                        print(f"   [1] {op} address v{r} still in flight (#{idx})"); bad += 1
-                for r in dst:
-                    if r in mfma_read_ab and n_mfma - mfma_read_ab[r] < 1:
-                        print(f"   [4] {op} lands in v{r}, read by the MFMA issued just before (#{idx})"); bad += 1
-                pending.append(dst)
-                inflight.update(dst)
-                continue
-            if op.startswith("buffer_load"):
-                srcs = regs(ops[0])
-                dst = []
-            for r in srcs + (dst if not op.startswith("v_mfma") else []):
-                if r in inflight:
-                    print(f"   [1] {op} touches v{r} while its LDS read is in flight (#{idx})"); bad += 1
-            if op.startswith("v_mfma"):
-                for r in srcs:
-                    if r in valu_written and idx - valu_written[r] < 3:      # >= 2 instructions strictly between
-                        print(f"   [2] {op} reads v{r} written by a VALU instruction {idx - valu_written[r] - 1} instructions earlier (#{idx})"); bad += 1
-                for r in regs(ops[1]) + regs(ops[2]):
-                    mfma_read_ab[r] = n_mfma + 1
-                n_mfma += 1
-                for r in dst:
-                    mfma_written[r] = idx
-                continue
-            for r in srcs + dst:
-                if r in mfma_written:
-                    ws = sum(8 if loop[k][0].startswith("v_mfma") else 1 for k in range(mfma_written[r] + 1, idx))
-                    if ws < 12:
-                        print(f"   [3] {op} touches v{r}, an MFMA result only {ws} wait states old (#{idx})"); bad += 1
-            if op.startswith("v_") and not op.startswith("v_cmp"):
-                for r in dst:
-                    valu_written[r] = idx
-        if pending and False:
-            pass
+        finds = check(loop)
+        # the back edge: the steady-state bodies once more behind themselves (lazy loop: il_loop .. the backward s_branch; x4: the same), and every body of the
+        # exact loop behind every other (its four bodies follow each other in any order)
+        segs, curseg = [], None
+        for op_, o_ in ins[first:last]:
+            if op_ == "label":
+                curseg = [o_[0], []]
+                segs.append(curseg)
+            elif curseg is not None:
+                curseg[1].append((op_, o_))
+        steady = next((sg[1] for sg in segs if sg[0].startswith("il_loop") or sg[0].startswith("x4_loop")), None)
+        if steady:
+            cut = next((k for k, (op_, _) in enumerate(steady) if op_ == "s_branch"), len(steady) - 1) + 1
+            finds += ["(back edge) " + f_ for f_ in check(steady[:cut] + steady[:cut], report_from=cut)]
+        xb = [sg[1] for sg in segs if sg[0].startswith("ix_b")]
+        for a_ in xb:
+            for b_ in xb:
+                finds += ["(body pair) " + f_ for f_ in check(a_ + b_, report_from=len(a_))]
+        for f_ in finds:
+            print(f_)
+        bad += len(finds)
         branches = [i for i, (op, _) in enumerate(loop) if "branch" in op]
         print(f"   branches inside the loop: {len(branches)}; findings: {bad}")
     if not found:
         print("no hand-scheduled tile loop found in", obj)
-        sys.exit(2)
+        sys.exit(0 if allow_missing else 2)
     sys.exit(1 if bad else 0)
 
 

@@ -42,6 +42,8 @@ EXPD = int(os.environ.get("TFA_GEN_EXPD", "1"))            # an element's exp2 i
 TILE = 16384                                               # bytes of a K / V tile in LDS: 64 * D * 2 (set per text)
 MFMA = "v_mfma_f32_32x32x16_bf16"                          # set per dtype by main()
 CVT = "v_cvt_pk_bf16_f32"
+WITH_TAIL = int(os.environ.get("TFA_GEN_TAIL", "1"))   # the lazy-reference statements also carry the bodies behind the loop (round 6): dispatch, N / M / L per parity
+KSTEP = 1                                                  # tiles of the head between two tiles of a wave (key-split kernels: 2)
 NBUF = int(os.environ.get("TFA_GEN_NBUF", "4"))    # experiment knob: fewer fragment buffers (WRONG results below 4 with this schedule: register-pressure probe only)
 
 # operands whose register NUMBER the text needs (sub-registers of a tuple, or single registers used inside v[..] expressions): name -> asm symbol
@@ -88,11 +90,36 @@ def frag_reads(g, par):
             f"ds_read_b64_tr_b16 {frag(g, 2, 2)}, %[va] offset:{off + 256}"]
 
 
-def body(par, lbl, exact=False, resc=False):
+def mask_ko(e):
+    """key offset inside the tile of S element e (0..31) of a lane with hi = 0: 32 * key block + (r & 3) + 8 * (r >> 2) — tfa_fwd_kernel_il.h: apply_mask"""
+    tt, r = e >> 4, e & 15
+    return 32 * tt + (r & 3) + 8 * (r >> 2)
+
+
+def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
+    """One tile body.  tail: a body OUTSIDE the loop (round 6) — no loop control behind the barrier, the K(j+2) request only when %[ik] != 0 (a wave's
+    last tiles: K(j+2) may lie behind the block's last tile); mask: S(j+1) is the wave's masked (diagonal / ragged) tile — element e becomes -inf where
+    its key offset exceeds the lane's limit %[lim], two VALU per element in front of the row maximum that reads it"""
     cur, nxt = ("a", "b") if par == 0 else ("b", "a")
     o = []
     a = o.append
     a(f"; ---- tile of parity {par}: S(j) in s{cur} -> P, O += P V(j); S(j+1) = K(j+1) Q^T -> s{nxt}")
+    if mask:
+        # the lane's mask limit for tile j + 1, in the (dead) maximum of tile j: lane & 31 (its row inside the wave) - 4 * (lane >> 5) (the half-wave's key offset,
+        # apply_mask) + slim - 64 * (j + 1 - fmx), slim = the wave's first row + the causal shift - the first key of tile fmx (a scalar).  The tails only run on
+        # blocks whose tiles all lie inside the keys, so the key-count bound of apply_mask never binds.  thr is scratch first, then holds -inf for the selects
+        a("v_mbcnt_lo_u32_b32 %[thr], -1, 0")
+        a("v_mbcnt_hi_u32_b32 %[thr], -1, %[thr]")
+        a("s_add_u32 %[ts], %[j], 1")
+        a("s_sub_u32 %[ts], %[ts], %[fmx]")
+        a(f"s_lshl_b32 %[ts], %[ts], {6 + (KSTEP - 1)}")
+        a("s_sub_u32 %[ts], %[slim], %[ts]")
+        a(f"v_and_b32 %[m{cur}], 31, %[thr]")
+        a("v_lshrrev_b32 %[thr], 5, %[thr]")
+        a("v_lshlrev_b32 %[thr], 2, %[thr]")
+        a(f"v_sub_u32 %[m{cur}], %[m{cur}], %[thr]")
+        a(f"v_add_u32 %[m{cur}], %[ts], %[m{cur}]")
+        a("v_mov_b32 %[thr], 0xff800000")
     # fragments travel in pairs: at an even slot g fragment g+2 is requested in FRONT of the wait + MFMA g and fragment g+3 BEHIND MFMA g, so that a read
     # never lands in the buffer of the MFMA issued just before it (one MFMA of distance, what hipcc's own schedule keeps) and one s_waitcnt serves two MFMAs
     for g in (0, 1):
@@ -136,7 +163,13 @@ def body(par, lbl, exact=False, resc=False):
         if 0 <= gd < PPW:
             a(f"buffer_load_dwordx4 %[vs{gd}], %[vrs], %[voff] offen lds")
         elif PPW <= gd < 2 * PPW:
+            if tail:                                       # (behind the loop tile j may be the block's last but one: K(j+2) exists only while j + 2 < nt)
+                a("s_add_u32 %[ts], %[j], 2")
+                a("s_cmp_ge_i32 %[ts], %[nt]")
+                a(f"s_cbranch_scc1 {lbl}_{'m' if mask else 'n'}{par}nok{gd}%=")
             a(f"buffer_load_dwordx4 %[ks{gd - PPW}], %[krs], %[koff] offen lds")
+            if tail:
+                a(f"{lbl}_{'m' if mask else 'n'}{par}nok{gd}%=:")
         if resc and g < N1 and N1 * 4 == 16 * DT:          # the re-basing body: O *= alpha rides behind the QK^T MFMAs, one register quad per MFMA
             for k in range(4):
                 a(f"v_mul_f32 v{192 + 4 * g + k}, v{192 + 4 * g + k}, %[alpha]")
@@ -156,6 +189,10 @@ def body(par, lbl, exact=False, resc=False):
         if g >= N1:                                        # row max of S(j+1): sixteen pairs of elements over the N2 slots of part 2
             for q in range(16):
                 if q * N2 // 16 == g - N1:
+                    if mask:                               # (both MFMA chains of S(j+1) are >= one MFMA old here: the distance the unmasked body's maximum keeps)
+                        for e in (2 * q, 2 * q + 1):
+                            a(f"v_cmp_le_i32 vcc, {mask_ko(e)}, %[m{cur}]")
+                            a(f"v_cndmask_b32 {S(nxt, e)}, %[thr], {S(nxt, e)}, vcc")    # (a literal next to vcc is two constant-bus reads: -inf sits in thr for the length of this body)
                     if q == 0:
                         a(f"v_max_f32 %[m{nxt}], {S(nxt, 0)}, {S(nxt, 1)}")
                     else:
@@ -165,15 +202,123 @@ def body(par, lbl, exact=False, resc=False):
     a("s_add_u32 %[j], %[j], 1")
     a("s_add_u32 %[koff], %[koff], %[kstr]")
     a("s_add_u32 %[voff], %[voff], %[vstr]")
+    if tail:                                               # on to the dispatch of the tile just produced (parity par ^ 1)
+        if mask:
+            a("v_add_f32 %[thr], 0x41000000, %[mref]")     # (thr held -inf for the mask)
+        a(f"s_branch {lbl}_d{par ^ 1}%=")
+        return o
     a("s_cmp_ge_i32 %[j], %[jend]")
     if not exact:
         a(f"v_mul_f32 v[F0], %[sc], %[m{nxt}]")            # (the fragment buffers are dead behind the last MFMA)
-        a(f"s_cbranch_scc1 {lbl}_exit%=")
+        a(f"s_cbranch_scc1 {lbl}_d{par ^ 1}%=" if WITH_TAIL else f"s_cbranch_scc1 {lbl}_exit%=")   # the loop's range ends here: the tile just produced goes to the dispatch
         a("v_cmp_gt_f32 vcc, v[F0], %[thr]")
         a(f"s_cbranch_vccnz {lbl}_exit%=")
     else:
         a(f"s_cbranch_scc1 {lbl}_exit%=")
         o.extend(exact_step(nxt, lbl))
+    return o
+
+
+def last_body(par, lbl):
+    """A wave's LAST tile of a pass (round 6; hipcc's burst-structured `slow` before): S(j) in the set of parity `par` -> P, O += P V(j), nothing else — no
+    S(j+1).  The softmax of P slot s + 1 rides behind the DT PV MFMAs of slot s (scale/subtract behind the first, exp2 behind the second, the sums and
+    the packs behind the rest), slot 0's in front of the first MFMA; V fragments in pairs as in the loop.  The wave still asks for its pieces of the
+    tiles the block's other waves go on to read: V(j+1) when %[iv] != 0, K(j+2) when %[ik] != 0.  Same operations in the same order per partial sum as
+    `slow`: bits identical."""
+    cur = "a" if par == 0 else "b"
+    o = []
+    a = o.append
+    a(f"; ---- last tile of a wave, parity {par}: S(j) in s{cur} -> P, O += P V(j)")
+
+    def vreads(i):
+        return frag_reads(N1 + i, par)
+
+    def soft(s, stage):
+        es = range(8 * s, 8 * s + 8)
+        if stage == 0:
+            return [f"v_fma_f32 {S(cur, e)}, {S(cur, e)}, %[sc], -%[mref]" for e in es]
+        if stage == 1:
+            return [f"v_exp_f32 {S(cur, e)}, {S(cur, e)}" for e in es]
+        if stage == 2:
+            return [f"v_add_f32 v[L{e & 3}], v[L{e & 3}], {S(cur, e)}" for e in es]
+        return [f"{CVT} {S(cur, 8 * s + k)}, {S(cur, 8 * s + 2 * k)}, {S(cur, 8 * s + 2 * k + 1)}" for k in range(4)]
+
+    # the four stages of a slot's softmax over the DT MFMAs of the slot before it
+    def share(s, k):
+        if DT == 4:
+            return soft(s, k)
+        return soft(s, 0) + soft(s, 1) if k == 0 else soft(s, 2) + soft(s, 3)
+
+    for i in (0, 1):
+        o.extend(vreads(i))
+    # the wave's LDS-DMA pieces first: nothing of this tile depends on them, and the other waves' next tiles do
+    a("s_add_u32 %[ts], %[j], 1")
+    for i in range(PPW):                                   # (s_add_u32 writes SCC: the test comes behind it; test + branch are the M0 write's wait states)
+        a(f"s_add_u32 m0, %[ldsw], {(2 + (par ^ 1)) * TILE + i * 1024}")
+        a("s_cmp_ge_i32 %[ts], %[nt]")
+        a(f"s_cbranch_scc1 {lbl}_l{par}nov{i}%=")
+        a(f"buffer_load_dwordx4 %[vs{i}], %[vrs], %[voff] offen lds")
+        a(f"{lbl}_l{par}nov{i}%=:")
+    a("s_add_u32 %[ts], %[j], 2")
+    for i in range(PPW):
+        a(f"s_add_u32 m0, %[ldsw], {par * TILE + i * 1024}")
+        a("s_cmp_ge_i32 %[ts], %[nt]")
+        a(f"s_cbranch_scc1 {lbl}_l{par}nok{i}%=")
+        a(f"buffer_load_dwordx4 %[ks{i}], %[krs], %[koff] offen lds")
+        a(f"{lbl}_l{par}nok{i}%=:")
+    for st in range(4):
+        o.extend(soft(0, st))
+    post = []
+    for i in range(N2):
+        if i % 2 == 0:
+            cnt = 0
+            if i + 2 < N2:
+                rs = vreads(i + 2)
+                o.extend(rs)
+                cnt = len(rs)
+            elif DT == 2:
+                a("s_nop 0")                               # (64 wide: slot 3's packs sit right behind MFMA N2 - 3; with no read left the wait alone is one wait state of the two)
+            a(f"s_waitcnt lgkmcnt({cnt})")
+            post = vreads(i + 3) if i + 3 < N2 else []
+        ob = 192 + 16 * (i % DT)
+        a(f"{MFMA} v[{ob}:{ob + 15}], {frag(N1 + i)}, {S(cur, 8 * (i // DT), 4)}, v[{ob}:{ob + 15}]")
+        if i % 2 == 0:
+            o.extend(post)
+        if i // DT + 1 < 4:
+            o.extend(share(i // DT + 1, i % DT))
+    a("s_waitcnt vmcnt(0)")
+    a("s_barrier")
+    a("s_add_u32 %[j], %[j], 1")
+    a(f"s_branch {lbl}_exit%=")
+    return o
+
+
+def tail_blocks(lbl):
+    """Behind the loop, in the same statement (round 6): per parity p of the tile j whose S the wave holds — the DISPATCH d<p> (leave for the compiler-scheduled
+    paths when the tails are off for this pass (fmx < 0) or a row of tile j has outgrown its reference; else j is the wave's last tile -> l<p>, tile j + 1 is
+    masked -> m<p>, or -> n<p>), and the three bodies: n<p> / m<p> run tile j like the loop's body (m: S(j+1) masked against the lane's limit) and go on to
+    d<p^1>; l<p> runs the last tile and leaves with j = nact."""
+    o = []
+    a = o.append
+    for par in (0, 1):
+        t = "a" if par == 0 else "b"
+        a(f"{lbl}_d{par}%=:")
+        a(f"v_mul_f32 v[F0], %[sc], %[m{t}]")
+        a("s_cmp_lt_i32 %[fmx], 0")
+        a(f"s_cbranch_scc1 {lbl}_exit%=")
+        a("v_cmp_gt_f32 vcc, v[F0], %[thr]")
+        a(f"s_cbranch_vccnz {lbl}_exit%=")
+        a("s_add_u32 %[ts], %[j], 1")
+        a("s_cmp_ge_i32 %[ts], %[nact]")
+        a(f"s_cbranch_scc1 {lbl}_l{par}%=")
+        a("s_cmp_ge_i32 %[ts], %[fmx]")
+        a(f"s_cbranch_scc1 {lbl}_m{par}%=")
+        a(f"{lbl}_n{par}%=:")
+        o.extend(body(par, lbl, tail=True))
+        a(f"{lbl}_m{par}%=:")
+        o.extend(body(par, lbl, tail=True, mask=True))
+        a(f"{lbl}_l{par}%=:")
+        o.extend(last_body(par, lbl))
     return o
 
 
@@ -223,10 +368,15 @@ def build(dtype, d=128, ppw=2):
     lines = list(head)
     a = lines.append
     a("v_add_f32 %[thr], 0x41000000, %[mref]")
+    if WITH_TAIL:                                          # entered at any even tile without a pending re-base: tiles below jend take the loop, the rest the dispatch
+        a("s_cmp_ge_i32 %[j], %[jend]")
+        a("s_cbranch_scc1 il_d0%=")
     a("il_loop%=:")
     lines.extend(body(0, "il"))
     lines.extend(body(1, "il"))
     a("s_branch il_loop%=")
+    if WITH_TAIL:
+        lines.extend(tail_blocks("il"))
     a("il_exit%=:")
     n_tile = sum(1 for l in body(0, "x") if not l.startswith(";"))
     # ---- the exact-running-max loop (VF_IL_EXACT, variant 38): per parity a plain body and one that also re-bases O; every body ends in the
