@@ -39,9 +39,18 @@
  *   O -> rounded to the input dtype (RNE), or left fp32 when out_dtype == TFA_F32
  *   LSE_i   = m_i + ln(l_i)   (natural log, scale included)  (flash_attention.cu:623)
  *   empty row (no visible key): O = 0, LSE = +inf            (flash_attention.cu:620-623)
- * Rounding points: the kernels that serve most shapes ("il" variants, see tfa_fwd_variant) form P against a
- * per-row reference exponent that trails the running max by at most 2^8 instead of the exact running max
- * (same O and LSE mathematically, P <= 2^8) — within the same tolerances as the exact rule.
+ * Rounding points (which row reference m' stands in P = exp(S - m') when P is rounded to 16 bits; O and LSE are the same numbers mathematically
+ * under every rule, and every rule holds the reference's atol 1e-2 and the rigorous bound |O - O_fp64| <= 2^-8 * A (bf16) / 2^-11 * A (fp16),
+ * A[i,d] = sum_j P[i,j] |v[j,d]| / l_i — tfa_fwd_rounding_rule says which one a call runs):
+ *   TFA_RULE_EXACT_MAX   the exact running maximum, the reference's own rule (flash_attention.cu:263-316, main_torch_only.py:240-260): the flag
+ *                        TFA_FWD_EXACT_MAX (element-wise rtol 1e-3 against the reference's tile loop), the split-KV kernel, fp32 tensors
+ *   TFA_RULE_LAZY        a per-row reference that trails the running maximum by at most 2^8 (P <= 2^8; a wave of 32 rows re-bases together when
+ *                        one of them outgrows it): fp16 on the default kernels, every special-case instantiation, head dims above 128
+ *   TFA_RULE_FIRST_TILE  bf16 on the default kernels' main instantiations (round 6): m' = the row's maximum over its FIRST 64-key tile, kept for
+ *                        the whole row — bf16 has fp32's exponent range, so no running maximum is needed for range, and the kernel forms none
+ *                        (it tests the row SUMS instead: beyond 2^40 a wave re-bases by an exact power of two, which moves no result bit; a
+ *                        single tile that lifts a row sum beyond 2^64 makes the workgroup redo that query block with TFA_RULE_LAZY).
+ *                        Stated domain: |v| * Nk < 2^63 (beyond it P*v could overflow fp32 before a re-base; the lazy rule's own limit is 2^119).
  *
  * Error convention: every entry point returns 0 on success, a negative tfa_status on a
  * rejected argument (nothing was launched), or a positive hipError_t when the HIP runtime
@@ -57,7 +66,7 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 109 /* 0.1.9: (b,h) slices of 2 GiB and more at head dims above 128 (windowed instantiations of the 256-wide forward and backward kernels; TFA_ERR_STRIDE before), tfa_debug_mfma_ceiling; 0.1.8: TFA_FWD_EXACT_MAX runs the il8 kernel's exact-max instantiation (variant 38) on grids that fill the chip; 0.1.7: tfa_bwd computes delta inside its dQ launch (tfa_debug_bwd_split bit 3 restores the separate launch), tfa_debug_set_trace is served by traced twins of the main kernels; 0.1.6: + fp32 q,k,v (TFA_F32 input: the correctness path behind the reference's fp32 fixtures), variant numbers are ids (tfa_variant_available), tfa_bwd_workspace_bytes is 0 wherever the workspace would be ignored; 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
+#define TFA_VERSION 110 /* 0.1.10: bf16 on the default kernels rounds P against the first key tile's row maximum (max-free tile loop; tfa_fwd_rounding_rule says which rule a call runs), the tile bodies behind the hand-scheduled loop are generated too, tfa_debug_mfma_ceiling returns TFA_ERR_SHAPE for bad sizes; 0.1.9: (b,h) slices of 2 GiB and more at head dims above 128 (windowed instantiations of the 256-wide forward and backward kernels; TFA_ERR_STRIDE before), tfa_debug_mfma_ceiling; 0.1.8: TFA_FWD_EXACT_MAX runs the il8 kernel's exact-max instantiation (variant 38) on grids that fill the chip; 0.1.7: tfa_bwd computes delta inside its dQ launch (tfa_debug_bwd_split bit 3 restores the separate launch), tfa_debug_set_trace is served by traced twins of the main kernels; 0.1.6: + fp32 q,k,v (TFA_F32 input: the correctness path behind the reference's fp32 fixtures), variant numbers are ids (tfa_variant_available), tfa_bwd_workspace_bytes is 0 wherever the workspace would be ignored; 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
 
 /* element types */
 enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1,
@@ -174,6 +183,14 @@ int tfa_fwd_plan(const tfa_fwd_params* p, int* grid, int* block, int* lds_bytes)
  * variants named "il..." keep a lazily re-based row reference instead of the exact running max
  * (oracle/oracle.py: tiled_emulation_lazy), all others follow main_torch_only.py:240-257 exactly. */
 int tfa_fwd_variant(const tfa_fwd_params* p);
+
+/* The row reference tfa_fwd would round P against for *p (the header's "Rounding points"): TFA_RULE_*, or a negative TFA_ERR_* code.  Decided
+ * by the same predicates as the launch (kernel variant, dtype, which instantiation of the variant the sizes select); the parity tests pick
+ * their same-rounding-points emulation with it (oracle/oracle.py: tiled_emulation, tiled_emulation_lazy, tiled_emulation_first_tile). */
+#define TFA_RULE_EXACT_MAX 0
+#define TFA_RULE_LAZY 1
+#define TFA_RULE_FIRST_TILE 2
+int tfa_fwd_rounding_rule(const tfa_fwd_params* p);
 
 /* Time `iters` back-to-back launches of *p with HIP events recorded on `stream`
  * (after `warmup` untimed launches).  Writes the average milliseconds per launch.

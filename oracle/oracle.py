@@ -232,23 +232,122 @@ def tiled_emulation_lazy(q, k, v, is_causal, softmax_scale, block_n=64, group=32
     return out
 
 
-def ksplit_emulation(q, k, v, is_causal, softmax_scale, block_n=64, return_lse=False, **kw):
+def tiled_emulation_first_tile(q, k, v, is_causal, softmax_scale, block_n=64, group=32, block_m=256, p_dtype=None,
+                               return_lse=False, key_pos=None, nk_total=None, row_pos=None, return_redo=False, force_redo=None):
+    """Rounding points of the MAX-FREE rule (round 6: bf16 instantiations of the il kernels that carry the hand-scheduled statement,
+    tiny-flash-attention_amd/csrc/tfa_fwd_kernel_il.h MAXFREE; include/tfa.h TFA_RULE_FIRST_TILE): every row keeps the reference exponent it
+    took from its FIRST key tile, ref = max_j s[i,j] * scale * log2e over that tile, for all tiles — P = exp2(s*c - ref) is rounded to bf16,
+    whose exponent range is fp32's, so no running maximum is needed for range and the kernel forms none.  What it tests is what it has summed: when a
+    row sum of a wave (``group`` rows) exceeds 2^40 behind a tile, the wave re-bases every row by an exact power of two (e = floor(log2 l);
+    ref += e, O and l *= 2^-e — no rounding in O or l; only fl(ref + e) can move later P by ~2^-19), and when a row sum exceeds 2^64 (or is not
+    finite) the workgroup REDOES that query block (``block_m`` rows): one more pass over the block's K tiles for the rows' true maxima, then the same
+    pass with ref SEEDED by them (P <= 1 throughout).  The kernel's trigger looks at a lane's partial sums (between 1/8 of the row sum and all of it):
+    the two can re-base at different tiles inside that band, which changes nothing but the rounding of ref + e.
+    ``return_redo``: also the (B, H, blocks) mask of redone blocks; ``force_redo``: a mask to OR into it (the key-split kernel: either wave group's)."""
+    B, H, Nq, D = q.shape
+    _, Hk, Nk, _ = k.shape
+    dt = q.dtype if p_dtype is None else p_dtype
+    qf = q.detach().cpu().float()
+    kf = k.detach().cpu().float()
+    vf = v.detach().cpu().float()
+    if Hk != H:
+        kf = kf.repeat_interleave(H // Hk, dim=1)
+        vf = vf.repeat_interleave(H // Hk, dim=1)
+    sc2 = torch.tensor(softmax_scale * 1.4426950408889634, dtype=torch.float32)
+    ngrp = (Nq + group - 1) // group
+    pad = ngrp * group - Nq
+    nblk = (Nq + block_m - 1) // block_m
+    rows = (torch.arange(Nq)[:, None] + ((Nk if nk_total is None else nk_total) - Nq)) if row_pos is None else row_pos[:, None]
+    pos = torch.arange(Nk) if key_pos is None else key_pos
+
+    def per_group_any(x):
+        og = torch.nn.functional.pad(x, (0, 0, 0, pad)).view(B, H, ngrp, group).any(dim=-1, keepdim=True)
+        return og.expand(B, H, ngrp, group).reshape(B, H, ngrp * group, 1)[:, :, :Nq]
+
+    def tile_scores(kv_start):
+        s = torch.matmul(qf, kf[:, :, kv_start:kv_start + block_n, :].transpose(2, 3))
+        if is_causal:
+            cols = pos[kv_start:kv_start + block_n][None, :]
+            s = s.masked_fill(cols > rows, -math.inf)
+        return s
+
+    def one_pass(seed):
+        acc = torch.zeros((B, H, Nq, D), dtype=torch.float32)
+        l = torch.zeros((B, H, Nq, 1), dtype=torch.float32)
+        ref = torch.full((B, H, Nq, 1), -1e30, dtype=torch.float32)
+        bad = torch.zeros((B, H, Nq, 1), dtype=torch.bool)
+        for ti, kv_start in enumerate(range(0, Nk, block_n)):
+            s = tile_scores(kv_start)
+            if ti == 0:                                                     # the first tile's maximum (fp32 product, as the kernel); O = l = 0 so far
+                ref = torch.maximum(ref, s.max(dim=-1, keepdim=True).values * sc2)
+                if seed is not None:
+                    ref = torch.maximum(ref, seed)
+            x = (s.double() * sc2.double() - ref.double()).float()          # one rounding, like v_fma_f32
+            pr = torch.exp2(x)
+            l = l + pr.sum(dim=-1, keepdim=True)
+            acc = acc + torch.matmul(pr.to(dt).float(), vf[:, :, kv_start:kv_start + block_n, :])
+            bad = bad | ~(l <= 2.0 ** 64)
+            trig = per_group_any(l > 2.0 ** 40)
+            if bool(trig.any()):
+                e = torch.floor(torch.log2(torch.where(torch.isfinite(l) & (l > 0), l, torch.ones_like(l)))).clamp(0, 126)
+                e = torch.where(trig, e, torch.zeros_like(e))
+                a = torch.exp2(-e)
+                l, acc, ref = l * a, acc * a, ref + e
+        empty = l == 0
+        out = torch.where(empty, torch.zeros_like(acc), acc / torch.where(empty, torch.ones_like(l), l))
+        lse = torch.where(empty, torch.full_like(l, math.inf), (ref + torch.log2(l)) * 0.6931471805599453).squeeze(-1)
+        return out, lse, bad
+
+    out, lse, bad = one_pass(None)
+    padm = nblk * block_m - Nq
+    redo = torch.nn.functional.pad(bad, (0, 0, 0, padm)).view(B, H, nblk, block_m).any(dim=-1)          # (B, H, blocks)
+    if force_redo is not None:
+        redo = redo | force_redo
+    if bool(redo.any()):
+        full = torch.full((B, H, Nq, 1), -math.inf, dtype=torch.float32)
+        for kv_start in range(0, Nk, block_n):
+            full = torch.maximum(full, tile_scores(kv_start).max(dim=-1, keepdim=True).values)
+        o2, l2, _ = one_pass(full * sc2)
+        rm = redo[..., None].expand(B, H, nblk, block_m).reshape(B, H, nblk * block_m)[:, :, :Nq]
+        out = torch.where(rm[..., None], o2, out)
+        lse = torch.where(rm, l2, lse)
+    res = (out, lse) if return_lse else (out,)
+    if return_redo:
+        res = res + (redo,)
+    return res if len(res) > 1 else res[0]
+
+
+def ksplit_emulation(q, k, v, is_causal, softmax_scale, block_n=64, return_lse=False, rule="lazy", **kw):
     """Rounding points of the key-split kernel (VF_IL_KSPLIT in tiny-flash-attention_amd/csrc/tfa_fwd_kernel_il.h):
     two wave groups run ``tiled_emulation_lazy`` over the even and the odd ``block_n``-key tiles of the sequence (causal
     mask against the positions in the whole sequence) and the two partial results are combined by the split-KV rule
     (tiny_flash_attn.py:63-68 / README_zh.md:104-125 restated in ``merge_partials``)."""
     Nk = k.shape[2]
     nt = (Nk + block_n - 1) // block_n
-    outs, lses = [], []
+    groups = []
     for g in (0, 1):
         idx = [torch.arange(t * block_n, min((t + 1) * block_n, Nk)) for t in range(g, nt, 2)]
-        if not idx:
-            continue
-        idx = torch.cat(idx)
-        o, l = tiled_emulation_lazy(q, k.detach().cpu()[:, :, idx], v.detach().cpu()[:, :, idx], is_causal, softmax_scale, block_n,
-                                    return_lse=True, key_pos=idx, nk_total=Nk, **kw)
-        outs.append(o)
-        lses.append(l)
+        if idx:
+            groups.append(torch.cat(idx))
+
+    def run(emulate, **extra):
+        res = [emulate(q, k.detach().cpu()[:, :, idx], v.detach().cpu()[:, :, idx], is_causal, softmax_scale, block_n,
+                       return_lse=True, key_pos=idx, nk_total=Nk, **kw, **extra) for idx in groups]
+        return res
+
+    if rule == "first_tile":
+        # ``rule``: each wave group keeps the maximum of ITS first tile (tile 0 / tile 1 of the head); a query block (128 rows) either group wants redone
+        # is redone by both (the workgroup agrees through one LDS word), each seeded with the row maxima over its own tiles
+        ft = run(tiled_emulation_first_tile, block_m=128, return_redo=True)
+        redo = ft[0][2]
+        for r in ft[1:]:
+            redo = redo | r[2]
+        if bool(redo.any()):
+            ft = run(tiled_emulation_first_tile, block_m=128, return_redo=True, force_redo=redo)
+        outs, lses = [r[0] for r in ft], [r[1] for r in ft]
+    else:
+        res = run(tiled_emulation_lazy)
+        outs, lses = [r[0] for r in res], [r[1] for r in res]
     out, lse = merge_partials(torch.stack(outs), torch.stack(lses))
     return (out, lse) if return_lse else out
 

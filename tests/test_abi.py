@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"include/tfa.h declares {n} but libtfa_hip.so does not export it"
     assert sorted(_lib.SYMBOLS) == names
-    assert L.tfa_version() == 109
+    assert L.tfa_version() == 110
 
 
 def _params(B=2, H=4, Hk=4, Nq=128, Nk=128, D=128, dtype=_lib.TFA_BF16, out_dtype=None, scale=0.1, base=0x10000):
@@ -56,15 +56,15 @@ def test_plan_geometry():
     st, grid, block, lds = plan(_params(**big))
     assert st == 0 and block == 256 and grid == 4 * 32 * 16 and lds == 4 * 64 * 128 * 2
     _lib.set_variant(-1)  # automatic: headline shape -> issue-interleaved kernel, 256-row blocks paired, 2 K + 2 V buffers
-    st, grid, block, lds = plan(_params(**big))   # + one 32-row epilogue slice per wave
-    assert st == 0 and block == 512 and grid == 4 * 32 * 8 and lds == 4 * 64 * 128 * 2 + 8 * 32 * 128 * 2
+    st, grid, block, lds = plan(_params(**big))   # + one 32-row epilogue slice per wave + the max-free rule's "redo this pass" word (16 bytes) and one seed per query row
+    assert st == 0 and block == 512 and grid == 4 * 32 * 8 and lds == 4 * 64 * 128 * 2 + 8 * 32 * 128 * 2 + 16 + 256 * 4
     # automatic, at most one 128-row block per CU (BASELINE config 2's shape, causal here) -> the key-split kernel: 8 waves per
     # 128-row block, unpaired, two groups of four tile buffers
     st, grid, block, lds = plan(_params(B=4, H=8, Hk=8, Nq=1024, Nk=1024, D=64, dtype=_lib.TFA_F16))
-    assert st == 0 and block == 512 and grid == 4 * 8 * 8 and lds == 8 * 64 * 64 * 2
+    assert st == 0 and block == 512 and grid == 4 * 8 * 8 and lds == 8 * 64 * 64 * 2 + 16 + 256 * 4
     # automatic, two 128-row blocks per CU -> 128-row blocks paired, two 4-wave workgroups per CU
     st, grid, block, lds = plan(_params(B=4, H=16, Hk=16, Nq=1024, Nk=1024, D=64, dtype=_lib.TFA_F16))
-    assert st == 0 and block == 256 and grid == 4 * 16 * 4 and lds == 4 * 64 * 64 * 2
+    assert st == 0 and block == 256 and grid == 4 * 16 * 4 and lds == 4 * 64 * 64 * 2 + 16 + 128 * 4
     if _lib.variant_available(1):   # A/B arms (make EXPERIMENTAL=1)
         _lib.set_variant(1)
         st, grid, block, lds = plan(_params(**big))
@@ -187,6 +187,27 @@ def test_gqa_packing_is_an_optimisation_never_a_requirement():
     st, grid, _, _ = plan(p)
     assert st == 0 and grid == 64 * 32
     assert _lib.lib().tfa_fwd_variant(C.byref(p)) == _lib.lib().tfa_fwd_variant(C.byref(_params(B=64, H=32, Hk=32, Nq=1, Nk=8192)))
+
+
+def test_rounding_rule_follows_dtype_variant_and_instantiation():
+    """tfa_fwd_rounding_rule (include/tfa.h: TFA_RULE_*): bf16 on the main instantiation of an il kernel keeps the first key tile's row maximum
+    (round 6, max-free); fp16, the special-case instantiations (a single partial query block: idle-wave form; head dims that leave the last column
+    block empty: narrow form), head dims above 128 re-base lazily; the flag, the split-KV kernel and fp32 tensors follow the exact running maximum."""
+    R = _lib.rule_for
+    assert R(4, 32, 32, 4096, 4096, 128, True) == _lib.RULE_FIRST_TILE                              # the headline: il8, bf16
+    assert R(4, 32, 32, 4096, 4096, 128, True, _lib.TFA_F16) == _lib.RULE_LAZY                      # fp16 P overflows at 2^16: keeps its maximum
+    assert R(4, 8, 8, 1024, 1024, 64, False) == _lib.RULE_FIRST_TILE                                # config 2's shape in bf16: il4, 64 wide
+    assert R(1, 8, 8, 4096, 4096, 128, True) == _lib.RULE_FIRST_TILE                                # the key-split kernel
+    assert R(4, 32, 32, 4096, 4096, 96, True) == _lib.RULE_LAZY                                     # narrow instantiation (last 32-column block empty)
+    assert R(64, 32, 32, 1, 8192, 128, True) == _lib.RULE_LAZY                                      # decode: the idle-wave instantiation
+    assert R(4, 8, 8, 4096, 4096, 256, True) == _lib.RULE_LAZY                                      # the 256-wide kernel
+    assert R(4, 32, 32, 4096, 4096, 128, True, flags=_lib.TFA_FWD_EXACT_MAX) == _lib.RULE_EXACT_MAX
+    _lib.set_variant(17)
+    try:
+        assert R(4, 32, 32, 4096, 4096, 128, True) == _lib.RULE_EXACT_MAX                           # the burst-structured kernel, forced
+    finally:
+        _lib.set_variant(-1)
+    assert _lib.lib().tfa_fwd_rounding_rule(None) == -1
 
 
 def test_exact_max_flag_selects_the_exact_running_max_kernel():

@@ -148,3 +148,33 @@ def test_kernel_emulations_stay_on_the_exact_result(oracle, causal):
     o2, l2 = oracle.tiled_emulation_lazy(qp, k2, v2, causal, sc, 64, return_lse=True, **kw)
     assert bool(((o2.reshape(ex2.shape) - ex2).abs() <= 2.0 ** -11 * A2 + 1e-6).all())
     assert (l2.reshape(lx2.shape) - lx2).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_first_tile_emulation_stays_on_the_exact_result(oracle, causal):
+    """The max-free rule (round 6, include/tfa.h TFA_RULE_FIRST_TILE: P rounded against the row maximum of the FIRST key tile; power-of-two re-bases of the
+    row sums; a query block whose row sum passes 2^64 redone with the lazy rule) restates the same function: pinned to exact64 inside the P-rounding
+    bound on plain data, on scores that climb past 2^40 (the re-base) and past 2^64 / into fp32 overflow (the redo), plain and through the key split."""
+    sc = 1.0 / math.sqrt(64)
+    q, k, v = oracle.make_inputs(1, 2, 300, 64, torch.bfloat16, seed=11, Nk=333)
+    cases = [("plain", q, k)]
+    for name, spikes in (("rebase", ((5, 200, 14.0), (130, 330, 10.0))), ("redo", ((7, 150, 22.0), (290, 320, 60.0), (131, 331, 16.0)))):
+        k2 = k.clone()
+        for row, key, gain in spikes:                                       # a late key aligned with one query row: its score jumps by ~ gain * |q|^2 / 8
+            k2[0, :, key] = (q[0, :, row].float() * gain).to(torch.bfloat16)
+        cases.append((name, q, k2))
+    for name, qq, kk in cases:
+        exact, lse_x = oracle.exact64(qq, kk, v, causal, sc, return_lse=True)
+        A = oracle.abs_weighted(qq, kk, v, causal, sc)
+        fin = torch.isfinite(lse_x)
+        o, l, redo = oracle.tiled_emulation_first_tile(qq, kk, v, causal, sc, 64, block_m=128, return_lse=True, return_redo=True)
+        assert bool(redo.any()) == (name == "redo"), (name, redo)
+        for tag, (o, l) in (("first_tile", oracle.tiled_emulation_first_tile(qq, kk, v, causal, sc, 64, block_m=128, return_lse=True)),
+                            ("ksplit", oracle.ksplit_emulation(qq, kk, v, causal, sc, 64, return_lse=True, rule="first_tile"))):
+            assert bool(torch.isfinite(o).all()), (name, tag)
+            assert bool(((o - exact).abs() <= 2.0 ** -8 * A + 1e-6).all()), (name, tag, ((o - exact).abs() - 2.0 ** -8 * A).max().item())
+            assert bool((torch.isinf(l) == ~fin).all()) and (l[fin] - lse_x[fin]).abs().max().item() <= 1e-4, (name, tag)
+    # without a re-base or a redo the rule differs from the lazy one only where the lazy one re-bases: on plain data the two coincide bit for bit
+    o_l = oracle.tiled_emulation_lazy(q, k, v, causal, sc, 64)
+    o_f = oracle.tiled_emulation_first_tile(q, k, v, causal, sc, 64)
+    assert bool((o_l == o_f).all())

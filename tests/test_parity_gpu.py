@@ -59,14 +59,22 @@ def _need_variant(variant, causal=False):
         pytest.skip(f"kernel variant {variant} is an A/B arm: not in the product build (make EXPERIMENTAL=1)")
 
 
-def check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype, var=None):
+def check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype, var=None, rule_of=None):
     """q,k,v: CPU tensors (B,H,Nq,D)/(B,Hk,Nk,D) of `dtype`; out*/lse: kernel results.  `var`: the kernel variant
     that produced them when q,k,v are only a slice of the problem the kernel saw (default: ask the library)."""
     from tiny_flash_attention_amd import _lib
 
     if var is None:
         var = _lib.variant_for(q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3], causal)
-    emulate = oracle.tiled_emulation_lazy if _lib.lazy_reference(var) else oracle.tiled_emulation
+    # which row reference the launch rounds P against (include/tfa.h: TFA_RULE_*): asked of the library for the problem as the KERNEL saw it
+    rule = _lib.rule_for(q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3], causal,
+                         _lib.TFA_BF16 if dtype == torch.bfloat16 else _lib.TFA_F16) if rule_of is None else rule_of
+    if not _lib.lazy_reference(var):
+        rule = _lib.RULE_EXACT_MAX                    # (a forced exact-max variant on a slice of a larger problem)
+    first_tile = rule == _lib.RULE_FIRST_TILE
+    bm = 256 if _lib.variant_name(var).startswith("il8-pair") else 128
+    emulate = ((lambda *a_, **k_: oracle.tiled_emulation_first_tile(*a_, block_m=bm, **k_)) if first_tile else
+               oracle.tiled_emulation_lazy if rule == _lib.RULE_LAZY else oracle.tiled_emulation)
     # GQA with few query rows and automatic dispatch: the library runs the G query heads of a K/V head as G x Nq rows of one
     # problem (tfa_api.hip: pack_gqa_rows) — same math, but a wave's 32 rows (the unit that re-bases together) now span heads
     Bq, Hq, Nqq, Dq = q.shape
@@ -77,7 +85,7 @@ def check(oracle, out16, out32, lse, q, k, v, causal, sc, dtype, var=None):
     qe, ce = (q.reshape(Bq, k.shape[1], G * Nqq, Dq), causal and with_pos) if packed else (q, causal)
     kw = {"row_pos": torch.arange(G * Nqq) % Nqq + (Nkk - Nqq)} if (packed and with_pos) else {}
     if var in (KSPLIT, KSPLIT_PAIR):                    # two wave groups over the even / odd key tiles, merged
-        emu, lse_e = oracle.ksplit_emulation(qe, k, v, ce, sc, 64, return_lse=True, **kw)
+        emu, lse_e = oracle.ksplit_emulation(qe, k, v, ce, sc, 64, return_lse=True, rule="first_tile" if first_tile else "lazy", **kw)
     else:
         emu, lse_e = emulate(qe, k, v, ce, sc, 64, return_lse=True, **kw)
     if packed:
@@ -477,6 +485,38 @@ def test_late_max_jump_spike(tfa, oracle, dev, variant):
         for causal in (False, True):
             out16, lse = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc)
             out32, _ = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc, out_f32=True)
+            check(oracle, out16, out32, lse, q, k, v, causal, sc, torch.bfloat16)
+    finally:
+        _lib.set_variant(-1)
+
+
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("variant", _avail([30, 32, 36, 37]))
+def test_max_free_rule_rebase_and_redo_spikes(tfa, oracle, dev, variant, D):
+    """Round 6, bf16 on the il kernels' main instantiations (include/tfa.h TFA_RULE_FIRST_TILE): the tile loop forms no row maximum — a row sum
+    beyond 2^40 re-bases the wave by an exact power of two, a row sum beyond 2^64 (or fp32 overflow) makes the workgroup redo the query block with the
+    lazily re-based rule.  Late keys aligned with single query rows drive scores ~2^50 (re-base), ~2^90 (redo) and past fp32's range (inf in P: redo)
+    above everything the row had seen; every output must stay finite and on the oracle, rows of untouched blocks included."""
+    from tiny_flash_attention_amd import _lib, ops
+
+    N = 1024
+    q, k, v = oracle.make_inputs(1, 2, N, D, torch.bfloat16, seed=23)
+    sc = 1.0 / math.sqrt(D)
+    norm2 = lambda r: float((q[0, 0, r].float() ** 2).sum())
+    # gain g on key `key` for row `row`: score = g * |q_row|^2 * sc nats = that * log2(e) binary orders
+    for row, key, orders in ((5, 700, 50.0), (300, 900, 90.0), (1000, 1001, 200.0), (37, 1023, 45.0), (640, 70, 100.0), (900, 64, 60.0)):
+        g = orders / 1.4426950408889634 / (norm2(row) * sc)
+        k[0, :, key] = (q[0, :, row].float() * g).to(torch.bfloat16)
+    _need_variant(variant)
+    _lib.set_variant(variant)
+    try:
+        for causal in (False, True):
+            if variant == KSPLIT_PAIR and not causal:
+                continue
+            assert _lib.rule_for(1, 2, 2, N, N, D, causal) == _lib.RULE_FIRST_TILE
+            out16, lse = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc)
+            out32, _ = ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), causal, sc, out_f32=True)
+            assert bool(torch.isfinite(out32).all()) and bool(torch.isfinite(out16.float()).all())
             check(oracle, out16, out32, lse, q, k, v, causal, sc, torch.bfloat16)
     finally:
         _lib.set_variant(-1)

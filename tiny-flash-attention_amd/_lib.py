@@ -18,6 +18,7 @@ SYMBOLS = (
     "tfa_fwd_bhnd_f32out",
     "tfa_fwd_plan",
     "tfa_fwd_variant",
+    "tfa_fwd_rounding_rule",
     "tfa_fwd_time",
     "tfa_set_variant",
     "tfa_get_variant",
@@ -151,6 +152,8 @@ def lib():
     L.tfa_get_variant.restype = C.c_int
     L.tfa_fwd_variant.restype = C.c_int
     L.tfa_fwd_variant.argtypes = [P]
+    L.tfa_fwd_rounding_rule.restype = C.c_int
+    L.tfa_fwd_rounding_rule.argtypes = [P]
     L.tfa_num_variants.restype = C.c_int
     L.tfa_variant_name.restype = C.c_char_p
     L.tfa_variant_name.argtypes = [C.c_int]
@@ -243,6 +246,33 @@ def variant_for(B, H, Hk, Nq, Nk, D, is_causal, dtype=TFA_BF16, flags=0):
     if v < 0:
         check(v)
     return v
+
+
+RULE_EXACT_MAX, RULE_LAZY, RULE_FIRST_TILE = 0, 1, 2
+
+
+def rounding_rule(p):
+    """The row reference tfa_fwd rounds P against for the problem *p (include/tfa.h: TFA_RULE_*)."""
+    r = lib().tfa_fwd_rounding_rule(C.byref(p))
+    if r < 0:
+        check(r)
+    return r
+
+
+def rule_for(B, H, Hk, Nq, Nk, D, is_causal, dtype=TFA_BF16, flags=0):
+    """rounding_rule for a contiguous (B,H,N,D) problem of these sizes (no GPU needed); honours a forced variant like variant_for."""
+    p = TfaFwdParams()
+    p.q = p.k = p.v = p.out = 0x1000
+    p.lse = None
+    p.B, p.H, p.Hk, p.Nq, p.Nk, p.D = B, H, Hk, Nq, Nk, D
+    for name, n, h in (("q_stride", Nq, H), ("k_stride", Nk, Hk), ("v_stride", Nk, Hk), ("o_stride", Nq, H)):
+        arr = getattr(p, name)
+        arr[0], arr[1], arr[2] = h * n * D, n * D, D
+    p.softmax_scale = 1.0
+    p.is_causal = 1 if is_causal else 0
+    p.dtype = p.out_dtype = dtype
+    p.flags = flags
+    return rounding_rule(p)
 
 
 def lazy_reference(v):

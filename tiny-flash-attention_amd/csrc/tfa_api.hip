@@ -66,7 +66,10 @@ int pick_variant(const tfa_fwd_params* p) {
     // rows, slices below 2 GiB — its exact-max instantiation (round 5); everywhere else the burst-structured LDS-DMA kernel
     tfa_fwd_params d = *p;
     d.flags &= ~TFA_FWD_EXACT_MAX;
-    return (pick_variant(&d) == tfa::kDefaultVariant && one_descriptor(p) && p->Nq > 256 - 32) ? tfa::kExactVariant : tfa::kSplitVariant;
+    // (variant 38 has the main instantiation only: the same rule the launch switch applies to variant 30 — tfa_launch.h: il_instantiation; packed rows never get here)
+    const bool main30 = pick_variant(&d) == tfa::kDefaultVariant &&
+                        tfa::il_instantiation(tfa::kDefaultVariant, !one_descriptor(p), p->Nq, 0, 128, 128) == tfa::IL_MAIN;
+    return main30 ? tfa::kExactVariant : tfa::kSplitVariant;
   }
   // Measured on MI355X (tests/tools/ab.py, profiles/): 256-row query blocks (8 waves) are fastest when there
   // are enough of them to fill 256 CUs and no causal diagonal; 128-row blocks (two 4-wave workgroups per
@@ -268,9 +271,10 @@ int run_f32(const tfa_fwd_params* p, void* stream, tfa::LaunchGeom* geom, bool d
   return (int)e;
 }
 
-int run(const tfa_fwd_params* p_in, void* stream, tfa::LaunchGeom* geom, bool dry, int* variant_out = nullptr) {
+int run(const tfa_fwd_params* p_in, void* stream, tfa::LaunchGeom* geom, bool dry, int* variant_out = nullptr, int* rule_out = nullptr) {
   if (p_in && p_in->dtype == TFA_F32) {
     if (variant_out) *variant_out = -1;
+    if (rule_out) *rule_out = TFA_RULE_EXACT_MAX;
     return run_f32(p_in, stream, geom, dry);
   }
   tfa_fwd_params packed;
@@ -291,6 +295,15 @@ int run(const tfa_fwd_params* p_in, void* stream, tfa::LaunchGeom* geom, bool dr
   }
   if (st != TFA_OK) return st;
   if (variant_out) *variant_out = variant;
+  if (rule_out) {
+    // the row reference P is rounded against (include/tfa.h): the il kernels' lazily re-based reference, except — bf16, the main instantiation (the one
+    // that carries the hand-scheduled statement: tfa_fwd_kernel_il.h MAXFREE) — the first key tile's maximum; the 256-wide kernel re-bases lazily too
+    const tfa::Variant* vi = tfa::variant_info(variant);
+    const bool il = vi && (vi->vf & tfa::VF_IL) != 0 && variant != tfa::kExactVariant;
+    const bool x4 = p->D > 128;
+    const bool main_inst = tfa::is_il_variant(variant) && tfa::il_instantiation(variant, a.big != 0, a.Nq, a.row_mod, a.dv, p->D > 64 ? 128 : 64) == tfa::IL_MAIN;
+    *rule_out = x4 ? TFA_RULE_LAZY : !il ? TFA_RULE_EXACT_MAX : (p->dtype == TFA_BF16 && main_inst && TFA_IL_USE_MAXFREE) ? TFA_RULE_FIRST_TILE : TFA_RULE_LAZY;
+  }
   const bool causal = p->is_causal != 0;
   const bool f32out = p->out_dtype == TFA_F32;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -554,6 +567,14 @@ int tfa_fwd_variant(const tfa_fwd_params* p) {
   const int st = run(p, nullptr, &g, true, &variant);
   if (st != 0) return st > 0 ? TFA_ERR_SHAPE : st;
   return variant;
+}
+
+int tfa_fwd_rounding_rule(const tfa_fwd_params* p) {
+  tfa::LaunchGeom g = {0, 0, 0};
+  int variant = -1, rule = -1;
+  const int st = run(p, nullptr, &g, true, &variant, &rule);
+  if (st != 0) return st > 0 ? TFA_ERR_SHAPE : st;
+  return rule;
 }
 
 int tfa_fwd_time(const tfa_fwd_params* p, int warmup, int iters, void* stream, float* avg_ms) {

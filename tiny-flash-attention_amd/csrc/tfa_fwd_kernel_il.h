@@ -109,6 +109,9 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
 #if !defined(TFA_IL_USE_ASMTAIL)
 #define TFA_IL_USE_ASMTAIL 1     // 0: the compiler-scheduled bodies outside the loop (the A/B arm of the round-6 tail bodies)
 #endif
+#if !defined(TFA_IL_USE_MAXFREE)
+#define TFA_IL_USE_MAXFREE 1     // 0: bf16 keeps the lazily re-based row reference with its per-tile row maximum (the A/B arm of the round-6 max-free rule)
+#endif
 #if !defined(TFA_IL_USE_ASMLOOP)
 #define TFA_IL_USE_ASMLOOP 1     // 0: the compiler-scheduled body everywhere (the A/B arm of the hand-scheduled steady state, tools/r5_arm.sh)
 #endif
@@ -326,6 +329,24 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
   constexpr bool PREF2 = PAIR && (VF & VF_IL_PREF2) != 0;
   constexpr bool QLDS = (VF & VF_IL_QLDS) != 0;
   constexpr bool EXACT = (VF & VF_IL_EXACT) != 0;
+  // MAX-FREE row reference (round 6; bf16 instantiations that carry the hand-scheduled statement): bf16 has fp32's exponent range, so P = exp2(s*c - mref)
+  // needs no running maximum for RANGE — mref stays the row's maximum over its FIRST key tile, the 16 v_max3 per tile are gone (-11.5 % of the tile's VALU
+  // work; +2.9 % on the headline) and what guards the fp32 sums is a test of what has been summed: a partial row sum beyond 2^40 leaves the statement and the
+  // wave re-bases by an exact power of two (mref += e, O and l *= 2^-e: no rounding, so the re-base moves no result bit).  A tile that lifts a row
+  // sum beyond 2^64 (a score 2^64 above everything the row had seen: the products P*v could overflow with it) is not repaired but the pass REDONE: the
+  // workgroup agrees through one LDS word behind the tile loop, streams the block's K tiles once more for the rows' TRUE maxima (S = K Q^T and its row
+  // maximum, nothing else), leaves them in LDS and runs the pass again with mref seeded by them (P <= 1: it cannot happen twice) — rare, 1.5 passes extra,
+  // correct, and no second rule in the tile bodies (a max-tracking twin of every body beside the max-free one made hipcc spill 90 registers).
+  // Stated domain: |v| * Nk < 2^63.  fp16 keeps the maximum (its P overflows at 2^16).  oracle/oracle.py: tiled_emulation_first_tile restates the rule.
+  constexpr bool MAXFREE_BASE = std::is_same<T, __bf16>::value && !EXACT && TFA_IL_USE_MAXFREE && TFA_IL_USE_ASMLOOP && (D == 128 || D == 64) && DVB == D / 32 &&
+                                (AB & ~ILAB_TRACE) == 0 && !(VF & (VF_IL_WINDOWED | VF_IL_IDLE | VF_IL_DMASTAGGER | VF_IL_SEAM)) && (PPW == 1 || PPW == 2 || PPW == 4);
+  constexpr bool MAXFREE = MAXFREE_BASE;
+  static_assert(!MAXFREE || !((VF & VF_IL_PREF) && !(VF & VF_IL_PREF2)), "max-free: a redone pass re-issues its own first requests (PREF2 or no prefetch)");
+  // behind everything else in LDS: one word "some row of this block needs the pass redone", then one float per query row of the block (the seeds of a redone pass)
+  constexpr int REDO_OFF = (KSPLIT ? 8 : 4) * TILE_BYTES + (((VF & VF_IL_EPI) && !(VF & VF_IL_EPI_INPLACE)) ? NW * 32 * D * 2 : 0);
+  constexpr int SEED_OFF = REDO_OFF + 16;
+  bool seeded = false;                                // this pass is a redone one: its rows take their reference from the seeds in LDS
+  if (MAXFREE && threadIdx.x == 0) *reinterpret_cast<volatile int*>(smem + REDO_OFF) = 0;   // (ordered before its first read by every pass's barriers)
   static_assert(!QLDS || ((VF & VF_IL_EPI) && !(VF & (VF_IL_EPI_INPLACE | VF_IL_KSPLIT | VF_IL_WINDOWED | VF_IL_IDLE | VF_IL_SEAM))), "QLDS: a wave-private slice of the separate epilogue region");
   // store instructions of O per pass and wave (the epilogue's three forms: fp32 direct, 16-bit rows through LDS, 16-bit direct)
   constexpr int NST_EPI = F32OUT ? 4 * DT : ((VF & VF_IL_EPI) ? 32 / (64 / (D / 8)) : 4 * DT);
@@ -513,7 +534,11 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     // exact-max rule, since SOME row of a wave nearly always sees a new max) out of the steady state; it lives in
     // the slow path below.  oracle/oracle.py:tiled_emulation_lazy restates this rule for the parity tests.
     float mref = -1e30f;
-    auto trigger = [&](float mloc) -> bool { return __any(mloc * sc > mref + 8.f); };
+    auto l_part_max = [&]() -> float { return fmaxf(fmaxf(l4[0], l4[1]), fmaxf(l4[2], l4[3])); };
+    auto trigger = [&](float mloc) -> bool {
+      if constexpr (MAXFREE) return __any(l_part_max() > 0x1p40f);          // max-free: what has been summed, not what is about to be
+      else return __any(mloc * sc > mref + 8.f);
+    };
     // (mloc may be the max over only this half-wave's 32 keys of the tile: the trigger is an OR over all lanes anyway;
     //  the re-base itself combines the two halves first so that both lanes of a row keep the same reference)
     // EXACT: the running maximum itself is the reference — nref = max(mref, tile max) for every row, every tile; rows whose maximum did not
@@ -533,6 +558,21 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #pragma unroll
           for (int i = 0; i < 4; ++i) l4[i] *= alpha;
           o_scale<DT>(alpha);
+        }
+      } else
+      if constexpr (MAXFREE) {
+        if (__any(l_part_max() > 0x1p40f)) {
+          // re-base by the row sum itself: e = floor(log2(l)) from the exponent field, alpha = 2^-e — exact in O and l (a sum that is inf / NaN already gets
+          // some factor: the pass is redone behind the loop anyway)
+          const float lt = pair_sum((l4[0] + l4[1]) + (l4[2] + l4[3]));
+          if (!(lt <= 0x1p64f)) *reinterpret_cast<volatile int*>(smem + REDO_OFF) = 1;   // beyond repair: the pass is redone behind the loop
+          int e = (int)((__builtin_bit_cast(unsigned, lt) >> 23) & 0xffu) - 127;
+          e = e < 0 ? 0 : (e > 126 ? 126 : e);
+          const float alpha = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) l4[i] *= alpha;
+          o_scale<DT>(alpha);
+          mref += (float)e;
         }
       } else
       if (__any(mloc * sc > mref + 8.f)) {
@@ -591,7 +631,42 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 
 #include "tfa_fwd_il_pass_prologue.inc"
 #include "tfa_fwd_il_tile_loop.inc"
+    if (MAXFREE && redo_pass) {
+      // (rare) this query block again.  First its rows' TRUE maxima: the block's K tiles once more through the (free) K buffers, S = K Q^T masked as in the
+      // pass, the row maximum, nothing else; into LDS, one float per row.  Then the pass from its first requests on, seeded (prologue): P <= 1 throughout
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is behind the tile loop and has read the word
+      *reinterpret_cast<volatile int*>(smem + REDO_OFF) = 0;
+      float mxr = -INFINITY;
+      if (nt > 0) dma_k(0, 0);
+#pragma nounroll
+      for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) { dma_k(t + 1, (t + 1) & 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (t < nact && !idle_wave) {
+          float mt;
+          qk_burst(t & 1, t, sA, mt);
+          mxr = fmaxf(mxr, mt);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");              // buffer t & 1 is refilled two tiles on
+      }
+      {
+        const int l_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        reinterpret_cast<volatile float*>(smem + SEED_OFF)[wave_id * 32 + (l_ & 31)] = mxr * sc;   // (both half-waves hold the row's maximum: qk_burst pairs them)
+      }
+      seeded = true;
+      if (PREF2) {                                     // (these kernels request a pass's first tiles and Q outside the pass body)
+        issue_prologue(mb, true);
+        o_zero<DT>();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s_ = 0; s_ < DS; ++s_) asm volatile("" : "+v"(qf[s_]));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      --pass;
+    } else {
 #include "tfa_fwd_il_epilogue.inc"
+    }
   }
 
   if (P_TRACE) {

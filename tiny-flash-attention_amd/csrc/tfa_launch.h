@@ -193,6 +193,24 @@ static inline bool windowed_slices(int variant) {
   return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kX4D256Variant;   // the dispatched il kernels and the 256-wide kernel have a windowed instantiation
 }
 
+// Which instantiation of an il variant a launch runs: ONE rule for the launch switch (tfa_fwd_inst.inc), for TFA_FWD_EXACT_MAX's choice of variant 38
+// (tfa_api.hip: pick_variant) and for tfa_fwd_rounding_rule — a (b,h) slice of 2 GiB and more takes the windowed form (il8 / il4 only), a single partial query
+// block or packed GQA rows the idle-wave form, head dims that leave the kernel's last 32-column block empty the narrow form (il8 / il4 only), else the MAIN
+// one: the instantiation with the hand-scheduled statement and, for bf16, the max-free row reference
+enum IlInst { IL_MAIN = 0, IL_WINDOWED = 1, IL_IDLE = 2, IL_NARROW = 3 };
+static inline IlInst il_instantiation(int variant, bool big, int Nq, int row_mod, int dv, int width) {
+  if (variant == kExactVariant) return IL_MAIN;            // (pick_variant only hands it problems the main il8 instantiation would take)
+  const bool has_special = variant == kDefaultVariant || variant == kSmallGridVariant;   // windowed / narrow forms exist
+  const int bm = variant == kDefaultVariant ? 256 : 128;
+  if (has_special && big) return IL_WINDOWED;
+  if (Nq <= bm - 32 || row_mod) return IL_IDLE;
+  if (has_special && dv <= width - 32) return IL_NARROW;
+  return IL_MAIN;
+}
+static inline bool is_il_variant(int variant) {
+  return variant == kDefaultVariant || variant == kSmallGridVariant || variant == kKSplitVariant || variant == kKSplitPairVariant || variant == kExactVariant;
+}
+
 static inline int block_m_of(int variant) {
   const Variant* v = variant_info(variant);
   if (!v) return 256;

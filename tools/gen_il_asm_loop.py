@@ -43,6 +43,8 @@ TILE = 16384                                               # bytes of a K / V ti
 MFMA = "v_mfma_f32_32x32x16_bf16"                          # set per dtype by main()
 CVT = "v_cvt_pk_bf16_f32"
 WITH_TAIL = int(os.environ.get("TFA_GEN_TAIL", "1"))   # the lazy-reference statements also carry the bodies behind the loop (round 6): dispatch, N / M / L per parity
+MAXFREE = False                                            # set by build() while it writes the max-free text (bf16 only): no row maximum of S(j+1), a guard on the partial row sums instead
+GUARD = "0x53800000"                                       # 2^40: a partial row sum beyond it leaves the statement for a re-base (87 binary orders below fp32 overflow)
 KSTEP = 1                                                  # tiles of the head between two tiles of a wave (key-split kernels: 2)
 NBUF = int(os.environ.get("TFA_GEN_NBUF", "4"))    # experiment knob: fewer fragment buffers (WRONG results below 4 with this schedule: register-pressure probe only)
 
@@ -157,6 +159,11 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
         else:
             i = g - N1
             ob = 192 + 16 * (i % DT)
+            # a pack that wrote this MFMA's P operand needs two instructions in front of the MFMA (the max-free texts have no row maximum left to fill the gap)
+            real = [l for l in o if not (l.startswith(";") or l.endswith(":"))]
+            since = next((k for k, l in enumerate(reversed(real)) if l.startswith(CVT)), 99)
+            if since < 2:
+                a(f"s_nop {1 - since}")
             a(f"{MFMA} v[{ob}:{ob + 15}], {frag(g)}, {S(cur, 8 * (i // DT), 4)}, v[{ob}:{ob + 15}]")
         if g % 2 == 0:
             o.extend(post)
@@ -193,6 +200,8 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
                         for e in (2 * q, 2 * q + 1):
                             a(f"v_cmp_le_i32 vcc, {mask_ko(e)}, %[m{cur}]")
                             a(f"v_cndmask_b32 {S(nxt, e)}, %[thr], {S(nxt, e)}, vcc")    # (a literal next to vcc is two constant-bus reads: -inf sits in thr for the length of this body)
+                    if MAXFREE:
+                        continue
                     if q == 0:
                         a(f"v_max_f32 %[m{nxt}], {S(nxt, 0)}, {S(nxt, 1)}")
                     else:
@@ -203,12 +212,19 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
     a("s_add_u32 %[koff], %[koff], %[kstr]")
     a("s_add_u32 %[voff], %[voff], %[vstr]")
     if tail:                                               # on to the dispatch of the tile just produced (parity par ^ 1)
-        if mask:
+        if mask and not MAXFREE:
             a("v_add_f32 %[thr], 0x41000000, %[mref]")     # (thr held -inf for the mask)
         a(f"s_branch {lbl}_d{par ^ 1}%=")
         return o
     a("s_cmp_ge_i32 %[j], %[jend]")
-    if not exact:
+    if not exact and MAXFREE:
+        # no maximum to test: the guard is on what has been SUMMED — a partial row sum beyond 2^40 (some P of this row was that large) leaves for a re-base
+        a("v_max3_f32 v[F0], v[L0], v[L1], v[L2]")        # (the fragment buffers are dead behind the last MFMA)
+        a("v_max_f32 v[F0], v[F0], v[L3]")
+        a(f"s_cbranch_scc1 {lbl}_d{par ^ 1}%=")
+        a(f"v_cmp_lt_f32 vcc, {GUARD}, v[F0]")
+        a(f"s_cbranch_vccnz {lbl}_x{par ^ 1}%=")
+    elif not exact:
         a(f"v_mul_f32 v[F0], %[sc], %[m{nxt}]")            # (the fragment buffers are dead behind the last MFMA)
         a(f"s_cbranch_scc1 {lbl}_d{par ^ 1}%=" if WITH_TAIL else f"s_cbranch_scc1 {lbl}_exit%=")   # the loop's range ends here: the tile just produced goes to the dispatch
         a("v_cmp_gt_f32 vcc, v[F0], %[thr]")
@@ -303,11 +319,19 @@ def tail_blocks(lbl):
     for par in (0, 1):
         t = "a" if par == 0 else "b"
         a(f"{lbl}_d{par}%=:")
-        a(f"v_mul_f32 v[F0], %[sc], %[m{t}]")
-        a("s_cmp_lt_i32 %[fmx], 0")
-        a(f"s_cbranch_scc1 {lbl}_exit%=")
-        a("v_cmp_gt_f32 vcc, v[F0], %[thr]")
-        a(f"s_cbranch_vccnz {lbl}_exit%=")
+        if MAXFREE:
+            a("v_max3_f32 v[F0], v[L0], v[L1], v[L2]")
+            a("v_max_f32 v[F0], v[F0], v[L3]")
+            a("s_cmp_lt_i32 %[fmx], 0")
+            a(f"s_cbranch_scc1 {lbl}_x{par}%=")
+            a(f"v_cmp_lt_f32 vcc, {GUARD}, v[F0]")
+            a(f"s_cbranch_vccnz {lbl}_x{par}%=")
+        else:
+            a(f"v_mul_f32 v[F0], %[sc], %[m{t}]")
+            a("s_cmp_lt_i32 %[fmx], 0")
+            a(f"s_cbranch_scc1 {lbl}_exit%=")
+            a("v_cmp_gt_f32 vcc, v[F0], %[thr]")
+            a(f"s_cbranch_vccnz {lbl}_exit%=")
         a("s_add_u32 %[ts], %[j], 1")
         a("s_cmp_ge_i32 %[ts], %[nact]")
         a(f"s_cbranch_scc1 {lbl}_l{par}%=")
@@ -319,6 +343,16 @@ def tail_blocks(lbl):
         o.extend(body(par, lbl, tail=True, mask=True))
         a(f"{lbl}_l{par}%=:")
         o.extend(last_body(par, lbl))
+    if MAXFREE:
+        # leaving with a tile in hand: the compiler-scheduled paths want its half-wave row maximum (the statement itself never formed it)
+        for par in (0, 1):
+            t = "a" if par == 0 else "b"
+            a(f"{lbl}_x{par}%=:")
+            a(f"v_max_f32 %[m{t}], {S(t, 0)}, {S(t, 1)}")
+            for q in range(1, 16):
+                a(f"v_max3_f32 %[m{t}], %[m{t}], {S(t, 2 * q)}, {S(t, 2 * q + 1)}")
+            if par == 0:
+                a(f"s_branch {lbl}_exit%=")
     return o
 
 
@@ -348,10 +382,12 @@ def emit(name, lines, n_tile, what):
     return out
 
 
-def build(dtype, d=128, ppw=2):
+def build(dtype, d=128, ppw=2, maxfree=False):
     """(lines of the lazy-reference loop, lines of the exact-running-max loop, instructions per tile of each body) for one 16-bit type, kernel width d
     (128 or 64) and ppw LDS-DMA pieces per wave and tensor (8-wave kernel: 2 / 1; 4-wave and key-split kernels: 4 / 2)"""
-    global MFMA, CVT, N1, N2, DT, DS, TILE, PPW
+    global MFMA, CVT, N1, N2, DT, DS, TILE, PPW, MAXFREE
+    MAXFREE = bool(maxfree)
+    assert not (maxfree and (dtype != "bf16" or not WITH_TAIL)), "max-free: bf16 only (a 16-bit P with fp32's exponent range), with the tails"
     DS, DT, TILE, PPW = d // 16, d // 32, 64 * d * 2, ppw
     N1, N2 = 2 * DS, 4 * DT
     for s_ in range(4):
@@ -367,7 +403,8 @@ def build(dtype, d=128, ppw=2):
     # ---- the lazy-reference loop (the headline kernel)
     lines = list(head)
     a = lines.append
-    a("v_add_f32 %[thr], 0x41000000, %[mref]")
+    if not MAXFREE:
+        a("v_add_f32 %[thr], 0x41000000, %[mref]")
     if WITH_TAIL:                                          # entered at any even tile without a pending re-base: tiles below jend take the loop, the rest the dispatch
         a("s_cmp_ge_i32 %[j], %[jend]")
         a("s_cbranch_scc1 il_d0%=")
@@ -381,6 +418,7 @@ def build(dtype, d=128, ppw=2):
     n_tile = sum(1 for l in body(0, "x") if not l.startswith(";"))
     # ---- the exact-running-max loop (VF_IL_EXACT, variant 38): per parity a plain body and one that also re-bases O; every body ends in the
     # exact_step of the tile it produced, which picks the next body
+    MAXFREE = False                                        # (the exact-running-max text below is what it is for)
     xl = list(head)
     a = xl.append
     xl.extend(exact_step("a", "ix"))
@@ -409,6 +447,10 @@ def main():
     out.extend(emit("TFA_IL_ASM_LOOP_F16", lines_h, n_tile, "fp16, lazy row reference"))
     out.extend(emit("TFA_IL_ASM_LOOP_EXACT", xl, n_x, "bf16, exact running maximum, the re-basing body"))
     out.extend(emit("TFA_IL_ASM_LOOP_EXACT_F16", xl_h, n_x, "fp16, exact running maximum, the re-basing body"))
+    # the max-free texts (bf16 only; every shape): no row maximum, a guard on the partial row sums
+    for d, ppw, stem in ((128, 2, ""), (128, 4, "_D128_P4"), (64, 1, "_D64_P1"), (64, 2, "_D64_P2")):
+        l_, _, n_, _, _ = build("bf16", d, ppw, maxfree=True)
+        out.extend(emit(f"TFA_IL_ASM_LOOP{stem}_MF", l_, n_, f"bf16, {d} wide, {ppw} pieces, max-free"))
     # the other tile shapes of fwd_kernel_il (lazy row reference only): 128 wide with 4 pieces per wave (the 4-wave and the key-split kernels), 64 wide with
     # 1 piece (8 waves) or 2 (4-wave / key-split)
     for d, ppw in ((128, 4), (64, 1), (64, 2)):
