@@ -100,11 +100,12 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
   asm volatile(TEXT \
   : [sa0] "+v"(sA[0]), [sa1] "+v"(sA[1]), [sb0] "+v"(sB[0]), [sb1] "+v"(sB[1]), \
   [l0] "+v"(l4[0]), [l1] "+v"(l4[1]), [l2] "+v"(l4[2]), [l3] "+v"(l4[3]), [ma] "+v"(mA), [mb] "+v"(mB), [mref] "+v"(mref), [j] "+s"(j), \
-  [koff] "+s"(koff), [voff] "+s"(voff), \
+  [koff] "+s"(koff), [voff] "+s"(voff), [ts] "=&s"(ts), \
   [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2), [f3] "=&v"(f3), [ka] "=&v"(ka), [ka5] "=&v"(ka5), [ka6] "=&v"(ka6), [ka7] "=&v"(ka7), [alpha] "=&v"(alpha) \
   : [q0] "v"(qf[0]), [q1] "v"(qf[1]), [q2] "v"(qf[2]), [q3] "v"(qf[3]), [q4] "v"(qf[4]), [q5] "v"(qf[5]), [q6] "v"(qf[6]), [q7] "v"(qf[7]), \
   [kaddr] "v"(k_rd_addr), [va] "v"(vaddr), [ks0] "v"(k_src[0]), [ks1] "v"(k_src[1]), [vs0] "v"(v_src[0]), [vs1] "v"(v_src[1]), \
-  [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend) \
+  [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend), \
+  [nact] "s"(nact_s), [fmx] "s"(fmx), [nt] "s"(nt_s), [slim] "s"(slim) \
   : TFA_O_CLOB0, TFA_O_CLOB1, TFA_O_CLOB2, TFA_O_CLOB3, "m0", "vcc", "scc", "memory")
 #if !defined(TFA_IL_USE_ASMTAIL)
 #define TFA_IL_USE_ASMTAIL 1     // 0: the compiler-scheduled bodies outside the loop (the A/B arm of the round-6 tail bodies)

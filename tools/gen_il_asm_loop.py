@@ -43,6 +43,7 @@ TILE = 16384                                               # bytes of a K / V ti
 MFMA = "v_mfma_f32_32x32x16_bf16"                          # set per dtype by main()
 CVT = "v_cvt_pk_bf16_f32"
 WITH_TAIL = int(os.environ.get("TFA_GEN_TAIL", "1"))   # the lazy-reference statements also carry the bodies behind the loop (round 6): dispatch, N / M / L per parity
+NINF = "thr"                                               # the operand a masked tail body parks -inf in: thr (lazy statements), alpha (the exact statement; dead behind exact_step's re-base)
 MAXFREE = False                                            # set by build() while it writes the max-free text (bf16 only): no row maximum of S(j+1), a guard on the partial row sums instead
 GUARD = "0x53800000"                                       # 2^40: a partial row sum beyond it leaves the statement for a re-base (87 binary orders below fp32 overflow)
 KSTEP = 1                                                  # tiles of the head between two tiles of a wave (key-split kernels: 2)
@@ -110,18 +111,18 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
         # the lane's mask limit for tile j + 1, in the (dead) maximum of tile j: lane & 31 (its row inside the wave) - 4 * (lane >> 5) (the half-wave's key offset,
         # apply_mask) + slim - 64 * (j + 1 - fmx), slim = the wave's first row + the causal shift - the first key of tile fmx (a scalar).  The tails only run on
         # blocks whose tiles all lie inside the keys, so the key-count bound of apply_mask never binds.  thr is scratch first, then holds -inf for the selects
-        a("v_mbcnt_lo_u32_b32 %[thr], -1, 0")
-        a("v_mbcnt_hi_u32_b32 %[thr], -1, %[thr]")
+        a(f"v_mbcnt_lo_u32_b32 %[{NINF}], -1, 0")
+        a(f"v_mbcnt_hi_u32_b32 %[{NINF}], -1, %[{NINF}]")
         a("s_add_u32 %[ts], %[j], 1")
         a("s_sub_u32 %[ts], %[ts], %[fmx]")
         a(f"s_lshl_b32 %[ts], %[ts], {6 + (KSTEP - 1)}")
         a("s_sub_u32 %[ts], %[slim], %[ts]")
-        a(f"v_and_b32 %[m{cur}], 31, %[thr]")
-        a("v_lshrrev_b32 %[thr], 5, %[thr]")
-        a("v_lshlrev_b32 %[thr], 2, %[thr]")
-        a(f"v_sub_u32 %[m{cur}], %[m{cur}], %[thr]")
+        a(f"v_and_b32 %[m{cur}], 31, %[{NINF}]")
+        a(f"v_lshrrev_b32 %[{NINF}], 5, %[{NINF}]")
+        a(f"v_lshlrev_b32 %[{NINF}], 2, %[{NINF}]")
+        a(f"v_sub_u32 %[m{cur}], %[m{cur}], %[{NINF}]")
         a(f"v_add_u32 %[m{cur}], %[ts], %[m{cur}]")
-        a("v_mov_b32 %[thr], 0xff800000")
+        a(f"v_mov_b32 %[{NINF}], 0xff800000")
     # fragments travel in pairs: at an even slot g fragment g+2 is requested in FRONT of the wait + MFMA g and fragment g+3 BEHIND MFMA g, so that a read
     # never lands in the buffer of the MFMA issued just before it (one MFMA of distance, what hipcc's own schedule keeps) and one s_waitcnt serves two MFMAs
     for g in (0, 1):
@@ -199,7 +200,7 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
                     if mask:                               # (both MFMA chains of S(j+1) are >= one MFMA old here: the distance the unmasked body's maximum keeps)
                         for e in (2 * q, 2 * q + 1):
                             a(f"v_cmp_le_i32 vcc, {mask_ko(e)}, %[m{cur}]")
-                            a(f"v_cndmask_b32 {S(nxt, e)}, %[thr], {S(nxt, e)}, vcc")    # (a literal next to vcc is two constant-bus reads: -inf sits in thr for the length of this body)
+                            a(f"v_cndmask_b32 {S(nxt, e)}, %[{NINF}], {S(nxt, e)}, vcc")    # (a literal next to vcc is two constant-bus reads: -inf sits in thr for the length of this body)
                     if MAXFREE:
                         continue
                     if q == 0:
@@ -212,7 +213,7 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
     a("s_add_u32 %[koff], %[koff], %[kstr]")
     a("s_add_u32 %[voff], %[voff], %[vstr]")
     if tail:                                               # on to the dispatch of the tile just produced (parity par ^ 1)
-        if mask and not MAXFREE:
+        if mask and not MAXFREE and NINF == "thr":
             a("v_add_f32 %[thr], 0x41000000, %[mref]")     # (thr held -inf for the mask)
         a(f"s_branch {lbl}_d{par ^ 1}%=")
         return o
@@ -230,7 +231,7 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
         a("v_cmp_gt_f32 vcc, v[F0], %[thr]")
         a(f"s_cbranch_vccnz {lbl}_exit%=")
     else:
-        a(f"s_cbranch_scc1 {lbl}_exit%=")
+        a(f"s_cbranch_scc1 {lbl}_d{par ^ 1}%=" if WITH_TAIL else f"s_cbranch_scc1 {lbl}_exit%=")
         o.extend(exact_step(nxt, lbl))
     return o
 
@@ -306,6 +307,39 @@ def last_body(par, lbl):
     a("s_barrier")
     a("s_add_u32 %[j], %[j], 1")
     a(f"s_branch {lbl}_exit%=")
+    return o
+
+
+def tail_blocks_exact(lbl):
+    """The exact-running-max statement's tails (variant 38): the dispatch d<p> advances the running maximum to tile j as the loop's bodies do (exact_step: mref, alpha,
+    l *= alpha) and, when some row of the wave moved, multiplies O by alpha in ONE burst (a tile or two per pass: no interleaved twin of every tail body); then
+    the same three bodies as the lazy statement — n<p>, m<p>, l<p> — which read mref as it stands."""
+    o = []
+    a = o.append
+    for par in (0, 1):
+        t = "a" if par == 0 else "b"
+        a(f"{lbl}_d{par}%=:")
+        a("s_cmp_lt_i32 %[fmx], 0")
+        a(f"s_cbranch_scc1 {lbl}_exit%=")
+        es = exact_step(t, lbl)
+        cut = next(k for k, l in enumerate(es) if l.startswith("s_cbranch_vccz"))
+        o.extend(es[:cut])
+        a(f"s_cbranch_vccz {lbl}_t{par}%=")
+        o.extend(es[cut + 1:-1])                           # the row sums take the factor (s_nop + 4 v_mul); no branch to a loop body
+        for r in range(192, 192 + 16 * DT):
+            a(f"v_mul_f32 v{r}, v{r}, %[alpha]")
+        a(f"{lbl}_t{par}%=:")
+        a("s_add_u32 %[ts], %[j], 1")
+        a("s_cmp_ge_i32 %[ts], %[nact]")
+        a(f"s_cbranch_scc1 {lbl}_l{par}%=")
+        a("s_cmp_ge_i32 %[ts], %[fmx]")
+        a(f"s_cbranch_scc1 {lbl}_m{par}%=")
+        a(f"{lbl}_n{par}%=:")
+        o.extend(body(par, lbl, tail=True))
+        a(f"{lbl}_m{par}%=:")
+        o.extend(body(par, lbl, tail=True, mask=True))
+        a(f"{lbl}_l{par}%=:")
+        o.extend(last_body(par, lbl))
     return o
 
 
@@ -419,14 +453,22 @@ def build(dtype, d=128, ppw=2, maxfree=False):
     # ---- the exact-running-max loop (VF_IL_EXACT, variant 38): per parity a plain body and one that also re-bases O; every body ends in the
     # exact_step of the tile it produced, which picks the next body
     MAXFREE = False                                        # (the exact-running-max text below is what it is for)
+    global NINF
+    NINF = "alpha"
     xl = list(head)
     a = xl.append
+    if WITH_TAIL:
+        a("s_cmp_ge_i32 %[j], %[jend]")
+        a("s_cbranch_scc1 ix_d0%=")
     xl.extend(exact_step("a", "ix"))
     for par in (0, 1):
         for resc in (False, True):
             a(f"ix_b{par}{'r' if resc else 'n'}%=:")
             xl.extend(body(par, "ix", exact=True, resc=resc))
+    if WITH_TAIL:
+        xl.extend(tail_blocks_exact("ix"))
     a("ix_exit%=:")
+    NINF = "thr"
     n_x = sum(1 for l in body(0, "x", exact=True, resc=True) if not l.startswith(";"))
     n_xn = sum(1 for l in body(0, "x", exact=True, resc=False) if not l.startswith(";"))
     return lines, xl, n_tile, n_xn, n_x
