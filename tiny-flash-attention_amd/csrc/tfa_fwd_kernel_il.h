@@ -238,6 +238,17 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     wi = r - rq * p.nwork;
     b = fd_div(kg, p.fd_wd);
     h = (kg - b * p.wd) * p.wg + rq;
+#if defined(TFA_IL_DECODE_WIMAJOR)
+    // measurement arm (never in the product; MHA with B * H a multiple of 8 only): on each XCD the work items in WORK-ITEM-major order — all heads of the XCD run
+    // their item 0, then item 1, .. — instead of head-major (a head's items back to back): profiles/r06_decode_order_pmc.txt
+    if (p.rr && p.wg == 1) {
+      const int hx = p.nbh >> 3;
+      wi = s / hx;
+      const int kg2 = x + 8 * (s - wi * hx);
+      b = kg2 / p.wd;
+      h = kg2 - b * p.wd;
+    }
+#endif
     hk = fd_div(h, p.fd_g);
     bh = b * p.H + h;
   }

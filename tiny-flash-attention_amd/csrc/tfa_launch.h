@@ -131,6 +131,7 @@ static inline void fill_decode(KArgs* a) {
   const int nwork = a->nwork > 0 ? a->nwork : 1;
   const bool gqa_rr = a->G > 1 && ((a->B * a->Hk) & 7) == 0;
   a->rr = (gqa_rr || (a->nbh & 7) == 0) ? 1 : 0;
+  if (a->dbg & 65536) a->rr = 0;     // measurement aid (tools/decode_order_pmc.sh): the plain order — a head's work items on consecutive workgroups, i.e. spread over all XCDs
   a->wa = gqa_rr ? a->G * nwork : nwork;
   a->wd = gqa_rr ? a->Hk : (a->H > 0 ? a->H : 1);
   a->wg = gqa_rr ? a->G : 1;
