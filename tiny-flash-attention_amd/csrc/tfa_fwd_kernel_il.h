@@ -376,7 +376,15 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
     return CAUSAL ? (p.nmb - 1 - wi) : wi;
   };
   // requests for the start of query block mbx: K(0), V(0), K(1) by LDS-DMA and this lane's Q fragments
+  // (round 6: what the per-pass code needs of the kernel arguments is read again from the kernarg segment through a laundered pointer — see the epilogue)
+  typedef __attribute__((address_space(4))) const KArgs kargs_c;
+  auto fresh_args = [&]() -> kargs_c* {
+    kargs_c* a_ = (kargs_c*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a_));
+    return a_;
+  };
   auto issue_prologue = [&](int mbx, bool with_dma) {
+    kargs_c& p = *fresh_args();                        // (shadows the kernel's `p` inside this lambda on purpose)
     const int q0x = mbx * BM;
     int kve = p.Nk;
     if (CAUSAL) {
@@ -645,7 +653,9 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 #include "tfa_fwd_il_tile_loop.inc"
     if (MAXFREE && redo_pass) {
       // (rare) this query block again.  First its rows' TRUE maxima: the block's K tiles once more through the (free) K buffers, S = K Q^T masked as in the
-      // pass, the row maximum, nothing else; into LDS, one float per row.  Then the pass from its first requests on, seeded (prologue): P <= 1 throughout
+      // pass, the row maximum, nothing else; into LDS, one float per row.  Then the epilogue below runs as for any pass — what it stores for this block is
+      // garbage the redone pass overwrites (same wave, same addresses, program order) — with THIS block as the "next" one: its requests, its O = 0; the pass
+      // counter steps back, and the pass that follows takes its row references from the seeds (prologue): P <= 1 throughout, it cannot happen twice
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is behind the tile loop and has read the word
       *reinterpret_cast<volatile int*>(smem + REDO_OFF) = 0;
       float mxr = -INFINITY;
@@ -666,19 +676,14 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
         const int l_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         reinterpret_cast<volatile float*>(smem + SEED_OFF)[wave_id * 32 + (l_ & 31)] = mxr * sc;   // (both half-waves hold the row's maximum: qk_burst pairs them)
       }
-      seeded = true;
-      if (PREF2) {                                     // (these kernels request a pass's first tiles and Q outside the pass body)
-        issue_prologue(mb, true);
-        o_zero<DT>();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int s_ = 0; s_ < DS; ++s_) asm volatile("" : "+v"(qf[s_]));
-      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      seeded = true;
       --pass;
-    } else {
-#include "tfa_fwd_il_epilogue.inc"
     }
+    // (the epilogue's "is there another pass, and for which block": a block to be redone is its own successor)
+    const bool more_passes = (MAXFREE && redo_pass) || pass + 1 < npass;
+    const int next_mb = (MAXFREE && redo_pass) ? mb : block_of(pass + 1);
+#include "tfa_fwd_il_epilogue.inc"
   }
 
   if (P_TRACE) {
