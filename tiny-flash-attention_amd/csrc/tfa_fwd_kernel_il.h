@@ -83,7 +83,8 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
 // (QOPS: the Q fragments of the kernel's width — 8 at 128, 4 at 64; SRCOPS: the lane offsets of the wave's DMA pieces — 1, 2 or 4 per tensor)
 // Round 6: the lazy-reference statement also carries the bodies BEHIND the loop (dispatch + pinned / masked / last-tile body per parity, tools/gen_il_asm_loop.py:
 // tail_blocks): [nact] the wave's tile count, [fmx] its first masked tile (-1: tails off — leave at jend as before), [nt] the block's tile count, [slim] the scalar part of the
-// lanes' mask limit for tile fmx (apply_mask's: the wave's first row + the causal shift - the tile's first key), [ts] a scratch scalar.  One statement, one register assignment: as statements of their own the tails made hipcc move
+// lanes' mask limit for tile fmx (apply_mask's: the wave's first row + the causal shift - the tile's first key), [ts] a scratch scalar, [xl] 0 / 1 = leave in front of the wave's last tile / 2 = run
+// that tile without the closing vmcnt wait (the early requests for a pair's second pass, below).  One statement, one register assignment: as statements of their own the tails made hipcc move
 // whole accumulator tuples through scratch between them (480 bytes per lane)
 #define TFA_IL_ASM_LAZY_STMT_G(TEXT, QOPS, SRCOPS) \
   asm volatile(TEXT \
@@ -93,7 +94,7 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
   [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2), [f3] "=&v"(f3), [ka] "=&v"(ka), [ka5] "=&v"(ka5), [ka6] "=&v"(ka6), [ka7] "=&v"(ka7), [thr] "=&v"(thr) \
   : QOPS, [mref] "v"(mref), [kaddr] "v"(k_rd_addr), [va] "v"(vaddr), SRCOPS, \
   [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend), \
-  [nact] "s"(nact_s), [fmx] "s"(fmx), [nt] "s"(nt_s), [slim] "s"(slim) \
+  [nact] "s"(nact_s), [fmx] "s"(fmx), [nt] "s"(nt_s), [slim] "s"(slim), [xl] "s"(xl) \
   : TFA_O_CLOB0, TFA_O_CLOB1, TFA_O_CLOB2, TFA_O_CLOB3, "m0", "vcc", "scc", "memory")
 #define TFA_IL_ASM_LAZY_STMT(TEXT) TFA_IL_ASM_LAZY_STMT_G(TEXT, TFA_IL_ASM_Q8, TFA_IL_ASM_SRC2)
 #define TFA_IL_ASM_EXACT_STMT(TEXT) \
@@ -109,6 +110,12 @@ constexpr int VF_IL_DMASTAGGER = 131072; // with DMASPREAD: the upper half of th
   : TFA_O_CLOB0, TFA_O_CLOB1, TFA_O_CLOB2, TFA_O_CLOB3, "m0", "vcc", "scc", "memory")
 #if !defined(TFA_IL_USE_ASMTAIL)
 #define TFA_IL_USE_ASMTAIL 1     // 0: the compiler-scheduled bodies outside the loop (the A/B arm of the round-6 tail bodies)
+#endif
+#if !defined(TFA_IL_USE_EARLY)
+#define TFA_IL_USE_EARLY 0       // 1: the early requests for a pair's second pass (round 6, issue_early below) — an A/B arm, measured and NOT shipped: the light prologue
+                                 // halves (3.1 k -> 1.5 k cycles) and epilogue + light pass lose 4.9 k, but the heavy pass's last iteration pays 2.5 k for the requests
+                                 // themselves (a wave's eight Q loads are 256 32-byte segments on the CU's one address path, whenever they are issued) and the
+                                 // launch comes out 0.3-1 % SLOWER in five spellings (profiles/r06_early_requests_ab.txt).  Default: PREF2's place, in the epilogue
 #endif
 #if !defined(TFA_IL_USE_MAXFREE)
 #define TFA_IL_USE_MAXFREE 1     // 0: bf16 keeps the lazily re-based row reference with its per-tile row maximum (the A/B arm of the round-6 max-free rule)
@@ -410,6 +417,31 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       qf[s] = __builtin_bit_cast(X8, t);
     }
   };
+  // EARLY requests for the second pass of a causal pair (round 6; VERDICT r05 item 1's "seam"): in the LAST iteration of the heavy pass both K buffers and V
+  // buffer 0 are idle (nt is even: V(nt-1) sits in buffer 1) and a wave's Q registers are dead (its last tile has no S(j+1)) — so every wave sends the light
+  // block's K(0), V(0), K(1) pieces and its Q rows THERE, a tile time before the epilogue would (PREF2), and nothing of that iteration waits for them.  The Q
+  // loads are inline asm into the registers in place ("+v"): hipcc's wait-count model does not see them (it would put a vmcnt(0) in front of the next pass's first
+  // MFMA, docs/LABLOG.md L-9 item 7); the epilogue's counted vmcnt does the waiting (one store more is younger than the requests: the LSE store)
+  auto issue_early = [&](int mbx) {
+    kargs_c& p = *fresh_args();
+    dma_k(0, 0);
+    dma_v(0, 0);
+    int one = 1;
+    asm volatile("" : "+s"(one));
+    dma_k(one, 1);
+    const int q0x = mbx * BM;
+    auto q_rs = slice_rsrc(qbase, p.q_bytes, (unsigned long long)q0x * (unsigned long long)p.qs_n * 2ull);
+    const int lane_p = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    int hix = lane_p >> 5;
+    asm volatile("" : "+v"(hix));
+    const int qoff = ((WIN ? 0 : q0x) + wrow * 32 + (lane_p & 31)) * (int)p.qs_n * 2 + hix * 16;
+    asm volatile("s_nop 4" ::: "memory");              // (a descriptor SALU code has just written -> VMEM: 5 wait states, and nothing pads an asm)
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+      const int off = (2 * s + hix) * 8 < p.dv ? qoff + s * 32 : (int)TFA_OOB;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(qf[s]) : "v"(off), "s"(q_rs) : "memory");
+    }
+  };
   // ---- QLDS: this wave's 32 rows of query block mbx into its slice of the epilogue region; the fragments out of it
   const unsigned q_slice = lds_base + 4 * TILE_BYTES + wave * (32 * D * 2);
   auto issue_q_dma = [&](int mbx) {
@@ -658,6 +690,13 @@ __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
       // counter steps back, and the pass that follows takes its row references from the seeds (prologue): P <= 1 throughout, it cannot happen twice
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is behind the tile loop and has read the word
       *reinterpret_cast<volatile int*>(smem + REDO_OFF) = 0;
+      if (early_done) {                                // (the early requests put the NEXT block's Q rows in the registers: this block's again, and the epilogue asks anew)
+        issue_prologue(mb, false);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s_ = 0; s_ < DS; ++s_) asm volatile("" : "+v"(qf[s_]));
+        early_done = false;
+      }
       float mxr = -INFINITY;
       if (nt > 0) dma_k(0, 0);
 #pragma nounroll

@@ -43,6 +43,7 @@ TILE = 16384                                               # bytes of a K / V ti
 MFMA = "v_mfma_f32_32x32x16_bf16"                          # set per dtype by main()
 CVT = "v_cvt_pk_bf16_f32"
 WITH_TAIL = int(os.environ.get("TFA_GEN_TAIL", "1"))   # the lazy-reference statements also carry the bodies behind the loop (round 6): dispatch, N / M / L per parity
+XL = True                                                  # the lazy statements take %[xl] (early requests for a pair's second pass, round 6); cleared while the exact statement's text is written
 NINF = "thr"                                               # the operand a masked tail body parks -inf in: thr (lazy statements), alpha (the exact statement; dead behind exact_step's re-base)
 MAXFREE = False                                            # set by build() while it writes the max-free text (bf16 only): no row maximum of S(j+1), a guard on the partial row sums instead
 GUARD = "0x53800000"                                       # 2^40: a partial row sum beyond it leaves the statement for a re-base (87 binary orders below fp32 overflow)
@@ -303,7 +304,12 @@ def last_body(par, lbl):
             o.extend(post)
         if i // DT + 1 < 4:
             o.extend(share(i // DT + 1, i % DT))
+    if XL:                                                 # (xl == 2: the next pass's first requests went out in front of this tile — nothing of THIS pass is in flight, and they must stay)
+        a("s_cmp_eq_u32 %[xl], 2")
+        a(f"s_cbranch_scc1 {lbl}_l{par}nw%=")
     a("s_waitcnt vmcnt(0)")
+    if XL:
+        a(f"{lbl}_l{par}nw%=:")
     a("s_barrier")
     a("s_add_u32 %[j], %[j], 1")
     a(f"s_branch {lbl}_exit%=")
@@ -368,13 +374,16 @@ def tail_blocks(lbl):
             a(f"s_cbranch_vccnz {lbl}_exit%=")
         a("s_add_u32 %[ts], %[j], 1")
         a("s_cmp_ge_i32 %[ts], %[nact]")
-        a(f"s_cbranch_scc1 {lbl}_l{par}%=")
+        a(f"s_cbranch_scc1 {lbl}_lq{par}%=")
         a("s_cmp_ge_i32 %[ts], %[fmx]")
         a(f"s_cbranch_scc1 {lbl}_m{par}%=")
         a(f"{lbl}_n{par}%=:")
         o.extend(body(par, lbl, tail=True))
         a(f"{lbl}_m{par}%=:")
         o.extend(body(par, lbl, tail=True, mask=True))
+        a(f"{lbl}_lq{par}%=:")                             # xl == 1: leave in front of the wave's last tile (the caller sends the next pass's first requests, then comes back with xl == 2)
+        a("s_cmp_eq_u32 %[xl], 1")
+        a(f"s_cbranch_scc1 {lbl}_x{par}%=" if MAXFREE else f"s_cbranch_scc1 {lbl}_exit%=")
         a(f"{lbl}_l{par}%=:")
         o.extend(last_body(par, lbl))
     if MAXFREE:
@@ -440,6 +449,8 @@ def build(dtype, d=128, ppw=2, maxfree=False):
     if not MAXFREE:
         a("v_add_f32 %[thr], 0x41000000, %[mref]")
     if WITH_TAIL:                                          # entered at any even tile without a pending re-base: tiles below jend take the loop, the rest the dispatch
+        a("s_bitcmp1_b32 %[j], 0")                         # (an odd tile — S in sb — only ever comes in for the dispatch: the wave's last tile behind the early requests)
+        a("s_cbranch_scc1 il_d1%=")
         a("s_cmp_ge_i32 %[j], %[jend]")
         a("s_cbranch_scc1 il_d0%=")
     a("il_loop%=:")
@@ -453,8 +464,8 @@ def build(dtype, d=128, ppw=2, maxfree=False):
     # ---- the exact-running-max loop (VF_IL_EXACT, variant 38): per parity a plain body and one that also re-bases O; every body ends in the
     # exact_step of the tile it produced, which picks the next body
     MAXFREE = False                                        # (the exact-running-max text below is what it is for)
-    global NINF
-    NINF = "alpha"
+    global NINF, XL
+    NINF, XL = "alpha", False
     xl = list(head)
     a = xl.append
     if WITH_TAIL:
@@ -468,7 +479,7 @@ def build(dtype, d=128, ppw=2, maxfree=False):
     if WITH_TAIL:
         xl.extend(tail_blocks_exact("ix"))
     a("ix_exit%=:")
-    NINF = "thr"
+    NINF, XL = "thr", True
     n_x = sum(1 for l in body(0, "x", exact=True, resc=True) if not l.startswith(";"))
     n_xn = sum(1 for l in body(0, "x", exact=True, resc=False) if not l.startswith(";"))
     return lines, xl, n_tile, n_xn, n_x
