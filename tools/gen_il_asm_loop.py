@@ -82,16 +82,17 @@ def frag(g, n=4, sub=0):
     return f"%[f{g % NBUF}]" if (n == 4 and sub == 0) else f"v[{b}+{sub}:{b}+{sub + n - 1}]"
 
 
-def frag_reads(g, par):
-    """ds_read instructions that bring fragment g (0..31) of the tile body into buffer g % 4"""
+def frag_reads(g, par, buf=None):
+    """ds_read instructions that bring fragment g (0..31) of the tile body into buffer g % 4 (buf: into the buffer of that index instead — bodies that leave fragments out)"""
+    b = g if buf is None else buf
     if g < N1:
         kt, ks = g & 1, g >> 1
         off = (par ^ 1) * TILE + kt * (TILE // 2)             # key block kt = rows 32 kt .. of the tile
-        return [f"ds_read_b128 {frag(g)}, {KADDR[ks]} offset:{off}"]
+        return [f"ds_read_b128 {frag(b)}, {KADDR[ks]} offset:{off}"]
     i = g - N1
     off = (2 + par) * TILE + (i // DT) * (2 * DT * 512) + (i % DT) * 512
-    return [f"ds_read_b64_tr_b16 {frag(g, 2, 0)}, %[va] offset:{off}",
-            f"ds_read_b64_tr_b16 {frag(g, 2, 2)}, %[va] offset:{off + 256}"]
+    return [f"ds_read_b64_tr_b16 {frag(b, 2, 0)}, %[va] offset:{off}",
+            f"ds_read_b64_tr_b16 {frag(b, 2, 2)}, %[va] offset:{off + 256}"]
 
 
 def mask_ko(e):
@@ -100,10 +101,21 @@ def mask_ko(e):
     return 32 * tt + (r & 3) + 8 * (r >> 2)
 
 
-def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
+def body(par, lbl, exact=False, resc=False, tail=False, mask=False, half=False):
     """One tile body.  tail: a body OUTSIDE the loop (round 6) — no loop control behind the barrier, the K(j+2) request only when %[ik] != 0 (a wave's
     last tiles: K(j+2) may lie behind the block's last tile); mask: S(j+1) is the wave's masked (diagonal / ragged) tile — element e becomes -inf where
-    its key offset exceeds the lane's limit %[lim], two VALU per element in front of the row maximum that reads it"""
+    its key offset exceeds the lane's limit %[lim], two VALU per element in front of the row maximum that reads it; half (with mask): the masked tile's SECOND
+    key block is hidden from every row of the wave (the diagonal's even waves: rows 0..31 of a 64-key tile see keys 0..31 at most) — its eight QK^T MFMAs and
+    their fragment reads are left out, its sixteen S registers are set to -inf outright"""
+    assert not half or (mask and tail)
+
+    # the fragments this body reads, in order; fragment al[k] travels in buffer k % 4 and in pairs by k (a body that leaves fragments out keeps the pairing and the
+    # one-MFMA distance between an MFMA and the next read into its buffer)
+    al = [g for g in range(N1 + N2) if not (half and g < N1 and (g & 1))]
+    ai = {g: k for k, g in enumerate(al)}
+
+    def reads(k):
+        return frag_reads(al[k], par, buf=k) if k < len(al) else []
     cur, nxt = ("a", "b") if par == 0 else ("b", "a")
     o = []
     a = o.append
@@ -126,25 +138,26 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
         a(f"v_mov_b32 %[{NINF}], 0xff800000")
     # fragments travel in pairs: at an even slot g fragment g+2 is requested in FRONT of the wait + MFMA g and fragment g+3 BEHIND MFMA g, so that a read
     # never lands in the buffer of the MFMA issued just before it (one MFMA of distance, what hipcc's own schedule keeps) and one s_waitcnt serves two MFMAs
-    for g in (0, 1):
-        o.extend(frag_reads(g, par))
+    for k in (0, 1):
+        o.extend(reads(k))
     if PRE:
-        o.extend(frag_reads(2, par))                       # (the slot-0 pre-read moves up as well: all three requests are out before the VALU work)
+        o.extend(reads(2))                                 # (the slot-0 pre-read moves up as well: all three requests are out before the VALU work)
         for e in range(PRE):
             a(f"v_fma_f32 {S(cur, e)}, {S(cur, e)}, %[sc], -%[mref]")
         for e in range(PRE):
             a(f"v_exp_f32 {S(cur, e)}, {S(cur, e)}")
     post = []
     for g in range(N1 + N2):
-        if g % 2 == 0:
+        k = ai.get(g)                                      # None: a fragment (and MFMA) this body leaves out — the slot keeps its share of the DMA and softmax work
+        if k is not None and k % 2 == 0:
             cnt = 0
-            if g + 2 < N1 + N2:
-                rs = frag_reads(g + 2, par)
-                if not (PRE and g == 0):
+            if k + 2 < len(al):
+                rs = reads(k + 2)
+                if not (PRE and k == 0):
                     o.extend(rs)
                 cnt = len(rs)
             a(f"s_waitcnt lgkmcnt({cnt})")
-            post = frag_reads(g + 3, par) if g + 3 < N1 + N2 else []
+            post = reads(k + 3)
         # LDS-DMA pieces behind the first four MFMAs: V(j+1) -> V buffer par^1, K(j+2) -> K buffer par.  m0 is written in FRONT of the slot's MFMA (which
         # is the wait state an M0 write needs before the load reads it); the source offset is the piece's lane offset (VGPR) plus the tile's byte offset
         # as the instruction's SCALAR offset — no VALU add.  The scalar offset takes no part in the descriptor's bounds check: the loop only requests tiles
@@ -157,7 +170,8 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
         if g < N1:
             kt, ks = g & 1, g >> 1
             c = "0" if ks == 0 else Sfull(nxt, kt)
-            a(f"{MFMA} {Sfull(nxt, kt)}, {frag(g)}, %[q{ks}], {c}")
+            if k is not None:
+                a(f"{MFMA} {Sfull(nxt, kt)}, {frag(k)}, %[q{ks}], {c}")
         else:
             i = g - N1
             ob = 192 + 16 * (i % DT)
@@ -166,8 +180,8 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
             since = next((k for k, l in enumerate(reversed(real)) if l.startswith(CVT)), 99)
             if since < 2:
                 a(f"s_nop {1 - since}")
-            a(f"{MFMA} v[{ob}:{ob + 15}], {frag(g)}, {S(cur, 8 * (i // DT), 4)}, v[{ob}:{ob + 15}]")
-        if g % 2 == 0:
+            a(f"{MFMA} v[{ob}:{ob + 15}], {frag(k)}, {S(cur, 8 * (i // DT), 4)}, v[{ob}:{ob + 15}]")
+        if k is not None and k % 2 == 0:
             o.extend(post)
         if 0 <= gd < PPW:
             a(f"buffer_load_dwordx4 %[vs{gd}], %[vrs], %[voff] offen lds")
@@ -175,10 +189,10 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
             if tail:                                       # (behind the loop tile j may be the block's last but one: K(j+2) exists only while j + 2 < nt)
                 a("s_add_u32 %[ts], %[j], 2")
                 a("s_cmp_ge_i32 %[ts], %[nt]")
-                a(f"s_cbranch_scc1 {lbl}_{'m' if mask else 'n'}{par}nok{gd}%=")
+                a(f"s_cbranch_scc1 {lbl}_{('mh' if half else 'm') if mask else 'n'}{par}nok{gd}%=")
             a(f"buffer_load_dwordx4 %[ks{gd - PPW}], %[krs], %[koff] offen lds")
             if tail:
-                a(f"{lbl}_{'m' if mask else 'n'}{par}nok{gd}%=:")
+                a(f"{lbl}_{('mh' if half else 'm') if mask else 'n'}{par}nok{gd}%=:")
         if resc and g < N1 and N1 * 4 == 16 * DT:          # the re-basing body: O *= alpha rides behind the QK^T MFMAs, one register quad per MFMA
             for k in range(4):
                 a(f"v_mul_f32 v{192 + 4 * g + k}, v{192 + 4 * g + k}, %[alpha]")
@@ -198,6 +212,10 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
         if g >= N1:                                        # row max of S(j+1): sixteen pairs of elements over the N2 slots of part 2
             for q in range(16):
                 if q * N2 // 16 == g - N1:
+                    if half and q >= 8:                    # the hidden key block: -inf outright (whoever takes the tile over — the last-tile body, the burst path — reads it so)
+                        for e in (2 * q, 2 * q + 1):
+                            a(f"v_mov_b32 {S(nxt, e)}, 0xff800000")
+                        continue
                     if mask:                               # (both MFMA chains of S(j+1) are >= one MFMA old here: the distance the unmasked body's maximum keeps)
                         for e in (2 * q, 2 * q + 1):
                             a(f"v_cmp_le_i32 vcc, {mask_ko(e)}, %[m{cur}]")
@@ -237,7 +255,7 @@ def body(par, lbl, exact=False, resc=False, tail=False, mask=False):
     return o
 
 
-def last_body(par, lbl):
+def last_body(par, lbl, half=False):
     """A wave's LAST tile of a pass (round 6; hipcc's burst-structured `slow` before): S(j) in the set of parity `par` -> P, O += P V(j), nothing else — no
     S(j+1).  The softmax of P slot s + 1 rides behind the DT PV MFMAs of slot s (scale/subtract behind the first, exp2 behind the second, the sums and
     the packs behind the rest), slot 0's in front of the first MFMA; V fragments in pairs as in the loop.  The wave still asks for its pieces of the
@@ -246,7 +264,9 @@ def last_body(par, lbl):
     cur = "a" if par == 0 else "b"
     o = []
     a = o.append
-    a(f"; ---- last tile of a wave, parity {par}: S(j) in s{cur} -> P, O += P V(j)")
+    NS = 2 if half else 4                                  # P slots that can hold anything but zeros (half: the tile's second key block is hidden from the whole wave)
+    NM = NS * DT                                           # PV MFMAs
+    a(f"; ---- last tile of a wave, parity {par}: S(j) in s{cur} -> P, O += P V(j)" + (" (first key block only)" if half else ""))
 
     def vreads(i):
         return frag_reads(N1 + i, par)
@@ -274,42 +294,42 @@ def last_body(par, lbl):
     for i in range(PPW):                                   # (s_add_u32 writes SCC: the test comes behind it; test + branch are the M0 write's wait states)
         a(f"s_add_u32 m0, %[ldsw], {(2 + (par ^ 1)) * TILE + i * 1024}")
         a("s_cmp_ge_i32 %[ts], %[nt]")
-        a(f"s_cbranch_scc1 {lbl}_l{par}nov{i}%=")
+        a(f"s_cbranch_scc1 {lbl}_l{'h' if half else ''}{par}nov{i}%=")
         a(f"buffer_load_dwordx4 %[vs{i}], %[vrs], %[voff] offen lds")
-        a(f"{lbl}_l{par}nov{i}%=:")
+        a(f"{lbl}_l{'h' if half else ''}{par}nov{i}%=:")
     a("s_add_u32 %[ts], %[j], 2")
     for i in range(PPW):
         a(f"s_add_u32 m0, %[ldsw], {par * TILE + i * 1024}")
         a("s_cmp_ge_i32 %[ts], %[nt]")
-        a(f"s_cbranch_scc1 {lbl}_l{par}nok{i}%=")
+        a(f"s_cbranch_scc1 {lbl}_l{'h' if half else ''}{par}nok{i}%=")
         a(f"buffer_load_dwordx4 %[ks{i}], %[krs], %[koff] offen lds")
-        a(f"{lbl}_l{par}nok{i}%=:")
+        a(f"{lbl}_l{'h' if half else ''}{par}nok{i}%=:")
     for st in range(4):
         o.extend(soft(0, st))
     post = []
-    for i in range(N2):
+    for i in range(NM):
         if i % 2 == 0:
             cnt = 0
-            if i + 2 < N2:
+            if i + 2 < NM:
                 rs = vreads(i + 2)
                 o.extend(rs)
                 cnt = len(rs)
             elif DT == 2:
-                a("s_nop 0")                               # (64 wide: slot 3's packs sit right behind MFMA N2 - 3; with no read left the wait alone is one wait state of the two)
+                a("s_nop 0")                               # (64 wide: the last slot's packs sit right behind MFMA NM - 3; with no read left the wait alone is one wait state of the two)
             a(f"s_waitcnt lgkmcnt({cnt})")
-            post = vreads(i + 3) if i + 3 < N2 else []
+            post = vreads(i + 3) if i + 3 < NM else []
         ob = 192 + 16 * (i % DT)
         a(f"{MFMA} v[{ob}:{ob + 15}], {frag(N1 + i)}, {S(cur, 8 * (i // DT), 4)}, v[{ob}:{ob + 15}]")
         if i % 2 == 0:
             o.extend(post)
-        if i // DT + 1 < 4:
+        if i // DT + 1 < NS:
             o.extend(share(i // DT + 1, i % DT))
     if XL:                                                 # (xl == 2: the next pass's first requests went out in front of this tile — nothing of THIS pass is in flight, and they must stay)
         a("s_cmp_eq_u32 %[xl], 2")
-        a(f"s_cbranch_scc1 {lbl}_l{par}nw%=")
+        a(f"s_cbranch_scc1 {lbl}_l{'h' if half else ''}{par}nw%=")
     a("s_waitcnt vmcnt(0)")
     if XL:
-        a(f"{lbl}_l{par}nw%=:")
+        a(f"{lbl}_l{'h' if half else ''}{par}nw%=:")
     a("s_barrier")
     a("s_add_u32 %[j], %[j], 1")
     a(f"s_branch {lbl}_exit%=")
@@ -376,16 +396,35 @@ def tail_blocks(lbl):
         a("s_cmp_ge_i32 %[ts], %[nact]")
         a(f"s_cbranch_scc1 {lbl}_lq{par}%=")
         a("s_cmp_ge_i32 %[ts], %[fmx]")
-        a(f"s_cbranch_scc1 {lbl}_m{par}%=")
+        a(f"s_cbranch_scc1 {lbl}_mq{par}%=")
         a(f"{lbl}_n{par}%=:")
         o.extend(body(par, lbl, tail=True))
+        # a masked tile whose SECOND key block no row of the wave sees (31 + slim - 64 (tile - fmx) < 32: the diagonal's even waves) takes the half forms:
+        # eight QK^T MFMAs, sixteen mask pairs, and — in the last-tile body — sixteen softmax elements and eight PV MFMAs less (1.5 % of a causal launch's MFMAs)
+        a(f"{lbl}_mq{par}%=:")
+        a("s_sub_u32 %[ts], %[ts], %[fmx]")
+        a(f"s_lshl_b32 %[ts], %[ts], {6 + (KSTEP - 1)}")
+        a("s_sub_u32 %[ts], %[slim], %[ts]")
+        a("s_cmp_le_i32 %[ts], 0")
+        a(f"s_cbranch_scc1 {lbl}_mh{par}%=")
         a(f"{lbl}_m{par}%=:")
         o.extend(body(par, lbl, tail=True, mask=True))
+        a(f"{lbl}_mh{par}%=:")
+        o.extend(body(par, lbl, tail=True, mask=True, half=True))
         a(f"{lbl}_lq{par}%=:")                             # xl == 1: leave in front of the wave's last tile (the caller sends the next pass's first requests, then comes back with xl == 2)
         a("s_cmp_eq_u32 %[xl], 1")
         a(f"s_cbranch_scc1 {lbl}_x{par}%=" if MAXFREE else f"s_cbranch_scc1 {lbl}_exit%=")
+        a("s_cmp_lt_i32 %[j], %[fmx]")                     # (an unmasked last tile — non-causal passes — has both key blocks)
+        a(f"s_cbranch_scc1 {lbl}_l{par}%=")
+        a("s_sub_u32 %[ts], %[j], %[fmx]")
+        a(f"s_lshl_b32 %[ts], %[ts], {6 + (KSTEP - 1)}")
+        a("s_sub_u32 %[ts], %[slim], %[ts]")
+        a("s_cmp_le_i32 %[ts], 0")
+        a(f"s_cbranch_scc1 {lbl}_lh{par}%=")
         a(f"{lbl}_l{par}%=:")
         o.extend(last_body(par, lbl))
+        a(f"{lbl}_lh{par}%=:")
+        o.extend(last_body(par, lbl, half=True))
     if MAXFREE:
         # leaving with a tile in hand: the compiler-scheduled paths want its half-wave row maximum (the statement itself never formed it)
         for par in (0, 1):
