@@ -688,6 +688,14 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_x4(const KArgs p) {
                        [sc] "s"(sc), [krs] "s"(k_rs), [vrs] "s"(v_rs), [ldsw] "s"(ldsw), [kstr] "s"(k_tile_stride), [vstr] "s"(v_tile_stride), [jend] "s"(jend) \
                      : TFA_X4_ALLCLOB, "m0", "vcc", "scc", "memory")
         constexpr bool BF = std::is_same<T, __bf16>::value;      // one text per (dtype, count of valid 32-column blocks)
+#if defined(TFA_X4_MF_ARM)     // timing arm (round 6; needs the file generated with TFA_GEN_X4_MF=1): the max-free texts under the lazy rule's C++ — same bits while no row
+                               // outgrows its reference.  +0.7 .. +1.1 % (profiles/r06_x4_maxfree_arm.txt): not built into a product rule for this kernel
+        if constexpr (DVB == 8 && BF) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V8_MF); }
+        else if constexpr (DVB == 7 && BF) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V7_MF); }
+        else if constexpr (DVB == 6 && BF) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V6_MF); }
+        else if constexpr (DVB == 5 && BF) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V5_MF); }
+        else
+#endif
         if constexpr (DVB == 8 && BF) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V8); }
         else if constexpr (DVB == 8) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V8_F16); }
         else if constexpr (DVB == 7 && BF) { TFA_X4_ASM_STMT(TFA_X4_ASM_LOOP_V7); }

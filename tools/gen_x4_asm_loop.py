@@ -30,6 +30,8 @@ DMA0, DMASTEP = 1, 1
 QBASE = 128
 MFMA = CVT = None
 NBUF = 8 if os.environ.get("TFA_GEN_X4_QUAD", "1") == "1" else 4     # fragment buffers: 8 = fragments travel in QUADS (one s_waitcnt per four MFMAs), 4 = pairs
+MAXFREE = False                          # set by build() while it writes a max-free text (bf16, round 6): no row maximum of S(t+1), a guard on the partial row sums (gen_il_asm_loop.py)
+GUARD = "0x53800000"                     # 2^40
 
 PARSED = {"sa0": "SA0", "sa1": "SA1", "sb0": "SB0", "sb1": "SB1", "l0": "L0", "l1": "L1", "l2": "L2", "l3": "L3",
           "f0": "F0", "f1": "F1", "f2": "F2", "f3": "F3", "ka": "KA", "kb": "KB"}
@@ -131,6 +133,8 @@ def body(t6):
                     a(f"{CVT} {S(cur, 8 * s + k)}, {S(cur, e - 1)}, {S(cur, e)}")
         # row max of S(t+1), two elements per instruction, from two MFMAs behind the end of its chains (slot N1+2) to the last slot
         for q in range(16):
+            if MAXFREE:
+                break
             if N1 + 2 + (q * (N2 - 2)) // 16 == g:
                 if q == 0:
                     a(f"v_max_f32 %[m{nxt}], {S(nxt, 0)}, {S(nxt, 1)}")
@@ -142,6 +146,13 @@ def body(t6):
     a("s_add_u32 %[koff], %[koff], %[kstr]")
     a("s_add_u32 %[voff], %[voff], %[vstr]")
     a("s_cmp_ge_i32 %[j], %[jend]")
+    if MAXFREE:                                            # what has been summed, not what is about to be: a partial row sum beyond 2^40 leaves for a re-base; every exit forms the
+        a(f"v_max3_f32 v[F{NBUF // 2}], v[L0], v[L1], v[L2]")    # maximum of the tile in hand on its way out (x4_x<parity>)
+        a(f"v_max_f32 v[F{NBUF // 2}], v[F{NBUF // 2}], v[L3]")
+        a(f"s_cbranch_scc1 x4_x{par ^ 1}%=")
+        a(f"v_cmp_lt_f32 vcc, {GUARD}, v[F{NBUF // 2}]")
+        a(f"s_cbranch_vccnz x4_x{par ^ 1}%=")
+        return o
     a(f"v_mul_f32 v[F{NBUF // 2}], %[sc], %[m{nxt}]")   # (the second half of the fragment buffers is dead here; the first half holds the next tile's first K fragments)
     a("s_cbranch_scc1 x4_exit%=")
     a(f"v_cmp_gt_f32 vcc, v[F{NBUF // 2}], %[thr]")
@@ -149,8 +160,10 @@ def body(t6):
     return o
 
 
-def build(dtype, dvb):
-    global MFMA, CVT, DT, N1, N2, TAIL
+def build(dtype, dvb, maxfree=False):
+    global MFMA, CVT, DT, N1, N2, TAIL, MAXFREE
+    MAXFREE = bool(maxfree)
+    assert not (maxfree and dtype != "bf16")
     DT = dvb
     N1 = N2 = 4 * DT
     TAIL = 3 * DT - 1
@@ -175,6 +188,15 @@ def build(dtype, dvb):
     for t6 in range(6):
         lines.extend(body(t6))
     a("s_branch x4_loop%=")
+    if MAXFREE:
+        for par in (0, 1):
+            t = "a" if par == 0 else "b"
+            a(f"x4_x{par}%=:")
+            a(f"v_max_f32 %[m{t}], {S(t, 0)}, {S(t, 1)}")
+            for q in range(1, 16):
+                a(f"v_max3_f32 %[m{t}], %[m{t}], {S(t, 2 * q)}, {S(t, 2 * q + 1)}")
+            if par == 0:
+                a("s_branch x4_exit%=")
     a("x4_exit%=:")
     return lines, len(body(0))
 
@@ -200,6 +222,9 @@ def main():
         lh, _ = build("f16", dvb)
         out.extend(emit(f"TFA_X4_ASM_LOOP_V{dvb}", lb, n, f"bf16, {dvb} column blocks"))
         out.extend(emit(f"TFA_X4_ASM_LOOP_V{dvb}_F16", lh, n, f"fp16, {dvb} column blocks"))
+        if os.environ.get("TFA_GEN_X4_MF", "0") == "1":    # the max-free texts: an ARM (round 6), not in the product file — priced at +0.7 .. +1.1 % (profiles/r06_x4_maxfree_arm.txt),
+            lm, nm = build("bf16", dvb, maxfree=True)      # half of the il kernels' gain (a 256-wide tile has twice the MFMAs per softmax element), not worth the redo machinery there
+            out.extend(emit(f"TFA_X4_ASM_LOOP_V{dvb}_MF", lm, nm, f"bf16, {dvb} column blocks, max-free"))
     print("\n".join(out))
 
 
