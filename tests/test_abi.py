@@ -609,13 +609,51 @@ def test_generated_tile_loops_are_in_sync_with_their_generators():
         assert out == have, f"{inc} is stale: re-run tools/{gen}"
 
 
+def test_generated_bodies_have_the_instruction_mix_the_docs_quote():
+    """Round 6: the statement's bodies, counted from the generator itself (DESIGN.md section 2 / LABLOG L-13 quote these numbers): the max-free loop body carries
+    115 VALU instructions per tile where the lazy one carries 130 (no v_max3 on S(j+1); a 3-instruction test of the row sums), every body its MFMAs — 32 in the
+    pinned and the masked body, 24 / 8 in the half forms of the diagonal's even waves, 16 in the last-tile body — and the masked body two VALU per masked element."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_il", os.path.join(root, "tools", "gen_il_asm_loop.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+
+    def mix(lines):
+        ins = [l for l in lines if not (l.startswith(";") or l.startswith(".") or l.endswith(":"))]
+        n = lambda pat: sum(1 for l in ins if re.match(pat, l))
+        return {"all": len(ins), "mfma": n(r"v_mfma"), "valu": n(r"v_(?!mfma)"), "exp": n(r"v_exp"), "max": n(r"v_max"), "lds": n(r"ds_read"), "dma": n(r"buffer_load")}
+
+    g.build("bf16", 128, 2)                                # sets the generator's shape globals; MAXFREE off
+    lazy = mix(g.body(0, "t"))
+    last, last_h = mix(g.last_body(0, "t")), mix(g.last_body(0, "t", half=True))
+    masked, masked_h = mix(g.body(0, "t", tail=True, mask=True)), mix(g.body(0, "t", tail=True, mask=True, half=True))
+    pinned = mix(g.body(0, "t", tail=True))
+    assert lazy["all"] == 242 and lazy["mfma"] == 32 and lazy["valu"] == 130 and lazy["exp"] == 32 and lazy["max"] == 16 and lazy["lds"] == 48 and lazy["dma"] == 4, lazy
+    assert pinned["mfma"] == 32 and pinned["valu"] == 128 and pinned["max"] == 16, pinned      # (no re-base test of its own: the dispatch behind it has it)
+    assert masked["mfma"] == 32 and masked["valu"] - pinned["valu"] == 64 + 9, masked        # 32 elements x (v_cmp + v_cndmask) + the lane's limit and -inf (8) + thr again (1)
+    assert masked_h["mfma"] == 24 and masked_h["lds"] == 40, masked_h                         # eight QK^T MFMAs and their fragment reads less
+    assert last["mfma"] == 16 and last["valu"] == 112 and last["lds"] == 32 and last["max"] == 0, last
+    assert last_h["mfma"] == 8 and last_h["valu"] == 56 and last_h["lds"] == 16, last_h
+    lines_mf, _, n_mf, _, _ = g.build("bf16", 128, 2, maxfree=True)
+    g.MAXFREE = True                                       # (build() leaves the switch off behind it: it writes the exact-running-max text last)
+    mf = mix(g.body(0, "t"))
+    assert n_mf == 227 and mf["all"] == 227 and mf["valu"] == 115 and mf["max"] == 2 and mf["mfma"] == 32, mf      # the two v_max are the test of the four partial row sums
+    assert sum(1 for l in lines_mf if re.match(r"il_x[01]%=:", l)) == 2                        # leaving with a tile in hand forms its maximum on the way out
+    g.build("bf16", 64, 1, maxfree=True)
+    g.MAXFREE = True
+    assert mix(g.body(0, "t"))["mfma"] == 16 and mix(g.body(0, "t"))["valu"] == 115
+
+
 def test_library_carries_the_hand_scheduled_loops():
     """The product library must contain the generated steady-state loops (their asm labels survive as local symbols of the code objects): a build with
     -DTFA_IL_USE_ASMLOOP=0 / -DTFA_X4_USE_ASMLOOP=0 — the A/B arms — is not what ships."""
     raw = open(_lib.LIB_PATH, "rb").read()
     # one label per kernel that carries a loop: the lazy-reference loop in 8 units x (il8, il4, key split, key split paired) x two output types, the exact loop in
     # the 128-wide causal / non-causal units of both types, the 256-wide loop in 32 units
-    for label, least in ((b"il_loop", 64), (b"ix_exit", 8), (b"x4_loop", 32)):
+    # (round 6: the statement carries the bodies behind the loop — dispatch, masked, half and last-tile bodies — and, in the bf16 units, the max-free texts' exits)
+    for label, least in ((b"il_loop", 64), (b"ix_exit", 8), (b"x4_loop", 32), (b"il_mh0", 64), (b"il_lh1", 64), (b"il_d1", 64), (b"il_x0", 32), (b"ix_l0", 8)):
         assert raw.count(label) >= least, f"{raw.count(label)} {label.decode()} labels in libtfa_hip.so, expected {least}: hand-scheduled loops are missing from this build"
     # ... and the windowed instantiations that (b,h) slices of 2 GiB and more run (round 5: the 256-wide forward kernel, VF | VF_X4_WINDOWED, and the 256-wide
     # backward kernel with BIG = true in all three modes)
