@@ -2,8 +2,8 @@
 """Static audit of the hand-scheduled tile loop (tfa_fwd_il_asm_loop.inc) on the DISASSEMBLED object — registers resolved, unlike the .s file, whose asm
 text still carries the assembler symbols.  usage: audit_il_asm_loop.py file.o [kernel-name substring]   (exit status 1 on any finding)
 
-Finds the loop (from its label-less head: the first ds_read_b128 behind the seven v_xor_b32 that build the K fragment addresses, to the backward
-s_branch) in every kernel that has one and checks, per tile body:
+Finds the statement (between its own labels: il_loop<N> .. il_exit<N>, ix_b.. .. ix_exit<N>, x4_loop<N> .. x4_exit<N>) in every kernel that has one and
+checks, over the linear instruction sequence, over the steady-state bodies once more behind themselves (the back edge) and over every pair of exact bodies:
   1. every LDS-read destination is complete (s_waitcnt lgkmcnt, LDS returns in order) before an instruction reads it;
   2. a VALU write of an MFMA A/B/C operand is >= 2 instructions in front of the MFMA;
   3. an MFMA result is >= 12 wait states old when a non-MFMA instruction reads or overwrites it (8-pass MFMA; an instruction between counts 1, an MFMA
@@ -82,8 +82,6 @@ def check(loop, report_from=0):
                     for r in pending.popleft():
                         inflight.discard(r)
             continue
-        if op.startswith("s_") and "branch" in op and not op.startswith("s_cbranch_scc1") and False:
-            pass
         if op in ("s_barrier",) or op.startswith("s_"):
             continue
         dst = regs(ops[0]) if ops else []
@@ -155,7 +153,6 @@ def main():
     for name, ins in kernels.items():
         if pat not in name:
             continue
-        # the loop: seven consecutive v_xor_b32 (K addresses), a v_add_f32 (thr), then bodies up to the backward s_branch
         # the loop lies between the asm statement's own labels: il_loop<N> .. il_exit<N> (lazy reference), the first ix_b.. label's exact_step .. ix_exit<N>
         labels = [(i, o[0]) for i, (op, o) in enumerate(ins) if op == "label"]
         first = next((i for i, n in labels if n.startswith("il_loop") or n.startswith("ix_b") or n.startswith("x4_loop")), None)
