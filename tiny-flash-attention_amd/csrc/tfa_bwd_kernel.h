@@ -22,6 +22,27 @@
 #pragma once
 #include "tfa_fwd_kernel_dma.h"
 #include "tfa_acc_regs.h"
+#if defined(TFA_BWD_DQ_ASM_INC)
+#include TFA_BWD_DQ_ASM_INC       // an A/B arm's text (tools/gen_bwd_dq_asm_loop.py with TFA_GEN_DQ_* set), never the product build
+#else
+#include "tfa_bwd_dq_asm_loop.inc"
+#endif
+
+#if !defined(TFA_BWD_DQ_USE_ASM)
+#define TFA_BWD_DQ_USE_ASM 1     // 0: the compiler-scheduled tile body everywhere (the A/B arm of the hand-scheduled dQ tiles, tools/gen_bwd_dq_asm_loop.py)
+#endif
+// The hand-scheduled unmasked tiles of the dQ launch: ONE statement (one register assignment), every operand the compiler's choice.
+#define TFA_BWD_DQ_ASM_STMT(TEXT) \
+  asm volatile(TEXT \
+  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [acc3] "+v"(acc[3]), [u] "+s"(ua), [koff] "+s"(koff), [voff] "+s"(voff), \
+  [s0] "=&v"(as0), [p0] "=&v"(ap0), [s1] "=&v"(as1), [p1] "=&v"(ap1), [f0] "=&v"(af0), [f1] "=&v"(af1), [f2] "=&v"(af2), [f3] "=&v"(af3), \
+  [ka] "=&v"(aka), [ka5] "=&v"(aka5), [ka6] "=&v"(aka6), [ka7] "=&v"(aka7) \
+  : [q0] "v"(r1f[0]), [q1] "v"(r1f[1]), [q2] "v"(r1f[2]), [q3] "v"(r1f[3]), [q4] "v"(r1f[4]), [q5] "v"(r1f[5]), [q6] "v"(r1f[6]), [q7] "v"(r1f[7]), \
+  [d0] "v"(r2f[0]), [d1] "v"(r2f[1]), [d2] "v"(r2f[2]), [d3] "v"(r2f[3]), [d4] "v"(r2f[4]), [d5] "v"(r2f[5]), [d6] "v"(r2f[6]), [d7] "v"(r2f[7]), \
+  [kaddr] "v"(a_kaddr), [vat] "v"(a_vat), [ks0] "v"(src[0][0]), [ks1] "v"(src[0][1]), [vs0] "v"(src[1][0]), [vs1] "v"(src[1][1]), \
+  [ts0] "v"(src[2][0]), [ts1] "v"(src[2][1]), [l2] "v"(lse2_lane), [dl] "v"(delta_lane), \
+  [sc] "s"(a_sc), [krs] "s"(rs_fixed[0]), [vrs] "s"(rs_fixed[1]), [ldsw] "s"(a_ldsw), [kstr] "s"(a_kstr), [vstr] "s"(a_vstr), [uend] "s"(a_uend) \
+  : "m0", "vcc", "scc", "memory")
 
 namespace tfa {
 
@@ -124,6 +145,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
   constexpr int NIMG = (UNI || MODE == BWD_DV) ? 2 : 3;   // LDS images per tile
   constexpr int IMG_TR = UNI ? (MODE == BWD_DV ? 1 : 0) : NIMG - 1;   // the image GEMM-II reads (UNI: dQ: K, dK: Q, dV: dO)
   static_assert(PPW >= 1 && PPW * NW == PIECES, "");
+  // the hand-scheduled unmasked tiles (tfa_bwd_dq_asm_loop.inc): the dQ launch of the 128-wide kernel.  Its LDS map puts the four row-major images first — every
+  // ds_read_b128 offset of the statement fits the instruction's 16-bit immediate — and the two transposed K images behind them
+  constexpr bool ASMDQ = TFA_BWD_DQ_USE_ASM != 0 && MODE == BWD_DQ && D == 128 && NW == 8 && !UNI && !BIG && DVB == 4;
+  auto img_off = [](int stage, int img) -> int {
+    if (ASMDQ) return img < 2 ? (2 * stage + img) * TILE_BYTES : (4 + stage) * TILE_BYTES;
+    return (stage * NIMG + img) * TILE_BYTES;
+  };
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -241,13 +269,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
         const auto rsw = rsrc_at(base, x.full, (unsigned long long)jt * (unsigned)tile_stride[img]);
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
-          lds_dma16_m0_fresh(rsw, lds_base + (stage * NIMG + img) * TILE_BYTES + (wave * PPW + i) * 1024, src[img][i]);
+          lds_dma16_m0_fresh(rsw, lds_base + img_off(stage, img) + (wave * PPW + i) * 1024, src[img][i]);
         continue;
       }
       auto rs = KEYS_RES ? __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, x.bytes, 0x00020000) : rs_fixed[img];
 #pragma unroll
       for (int i = 0; i < PPW; ++i)
-        lds_dma16_m0(rs, lds_base + (stage * NIMG + img) * TILE_BYTES + (wave * PPW + i) * 1024, src[img][i] + jt * tile_stride[img]);
+        lds_dma16_m0(rs, lds_base + img_off(stage, img) + (wave * PPW + i) * 1024, src[img][i] + jt * tile_stride[img]);
     }
     if (KEYS_RES && wave < 2) {
       // the tile's row statistics (LSE, delta: 64 rows = one dword per lane) travel with it — loaded from global memory by every lane
@@ -340,16 +368,44 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
   }
   asm volatile("s_barrier" ::: "memory");
 
+  // ---- the wave's unmasked, whole tiles 0 .. a_uend - 1, hand-scheduled (tile u + 1 must exist and lie wholly inside the keys: its LDS-DMA pieces take the tile's
+  //      byte offset as the SCALAR offset, which the descriptor's bounds check ignores); the loop below takes over at tile u0 with the same stage / barrier protocol
+  int u0 = 0;
+  if constexpr (ASMDQ) {
+    int a_uend = nu - 1;
+    { const int whole = p.Nk / BN - 1; a_uend = whole < a_uend ? whole : a_uend; }
+    if (CAUSAL) {
+      const int d = wave_row0 + shift - (BN - 1);            // last key of tile u <= the wave's first row's limit: u <= d / 64
+      const int lim = d >= 0 ? d / BN + 1 : 0;
+      a_uend = lim < a_uend ? lim : a_uend;
+    }
+    a_uend = __builtin_amdgcn_readfirstlane(a_uend);
+    if (a_uend > 0) {
+      f32x16 as0, ap0, as1, ap1;
+      u32x4 af0, af1, af2, af3, aka;
+      unsigned aka5, aka6, aka7;
+      const unsigned a_kaddr = lds_base + (unsigned)k_rd_base + ((unsigned)(hi ^ k_rd_swz) << 4);
+      const unsigned a_vat = lds_base + 4u * TILE_BYTES + (unsigned)v_rd_base;
+      const unsigned a_ldsw = __builtin_amdgcn_readfirstlane(lds_base + wave * (PPW * 1024));
+      const int a_kstr = __builtin_amdgcn_readfirstlane(tile_stride[0]), a_vstr = __builtin_amdgcn_readfirstlane(tile_stride[1]);
+      const float a_sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc)));
+      int ua = 0, koff = a_kstr, voff = a_vstr;
+      if constexpr (std::is_same<T, __bf16>::value) { TFA_BWD_DQ_ASM_STMT(TFA_BWD_DQ_ASM_LOOP); }
+      else { TFA_BWD_DQ_ASM_STMT(TFA_BWD_DQ_ASM_LOOP_F16); }
+      u0 = ua;
+    }
+  }
+
 #pragma nounroll
-  for (int u = 0; u < nu; ++u) {
+  for (int u = u0; u < nu; ++u) {
     const int stage = u & 1;
     if (u + 1 < nu) dma_issue(u + 1, stage ^ 1);     // the other stage was released by the barrier that ended tile u-1
     const int g = KEYS_RES ? u / ntl : 0;
     const int jt = t_begin + (u - g * ntl);
     const int row0 = jt * BN;                        // first streamed row of the tile (a key for dQ, a query for dK/dV)
-    const char* img0 = smem + (stage * NIMG + 0) * TILE_BYTES;
-    const char* img1 = smem + (stage * NIMG + 1) * TILE_BYTES;
-    const char* imgt = smem + (stage * NIMG + IMG_TR) * TILE_BYTES;
+    const char* img0 = smem + img_off(stage, 0);
+    const char* img1 = smem + img_off(stage, 1);
+    const char* imgt = smem + img_off(stage, IMG_TR);
 
     // does any element of this wave's 32 x 64 piece need masking?  is all of it masked (then the wave only keeps
     // the DMA and the barrier going)?

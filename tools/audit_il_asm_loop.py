@@ -2,7 +2,7 @@
 """Static audit of the hand-scheduled tile loop (tfa_fwd_il_asm_loop.inc) on the DISASSEMBLED object — registers resolved, unlike the .s file, whose asm
 text still carries the assembler symbols.  usage: audit_il_asm_loop.py file.o [kernel-name substring]   (exit status 1 on any finding)
 
-Finds the statement (between its own labels: il_loop<N> .. il_exit<N>, ix_b.. .. ix_exit<N>, x4_loop<N> .. x4_exit<N>) in every kernel that has one and
+Finds the statement (between its own labels: il_loop<N> .. il_exit<N>, ix_b.. .. ix_exit<N>, x4_loop<N> .. x4_exit<N>, dq_loop<N> .. dq_exit<N>) in every kernel that has one and
 checks, over the linear instruction sequence, over the steady-state bodies once more behind themselves (the back edge) and over every pair of exact bodies:
   1. every LDS-read destination is complete (s_waitcnt lgkmcnt, LDS returns in order) before an instruction reads it;
   2. a VALU write of an MFMA A/B/C operand is >= 2 instructions in front of the MFMA;
@@ -155,8 +155,8 @@ def main():
             continue
         # the loop lies between the asm statement's own labels: il_loop<N> .. il_exit<N> (lazy reference), the first ix_b.. label's exact_step .. ix_exit<N>
         labels = [(i, o[0]) for i, (op, o) in enumerate(ins) if op == "label"]
-        first = next((i for i, n in labels if n.startswith("il_loop") or n.startswith("ix_b") or n.startswith("x4_loop")), None)
-        last = next((i for i, n in labels if n.startswith("il_exit") or n.startswith("ix_exit") or n.startswith("x4_exit")), None)
+        first = next((i for i, n in labels if n.startswith("il_loop") or n.startswith("ix_b") or n.startswith("x4_loop") or n.startswith("dq_loop")), None)
+        last = next((i for i, n in labels if n.startswith("il_exit") or n.startswith("ix_exit") or n.startswith("x4_exit") or n.startswith("dq_exit")), None)
         if first is None or last is None:
             continue
         if any(n.startswith("ix_b") for _, n in labels):
@@ -181,7 +181,7 @@ def main():
                 segs.append(curseg)
             elif curseg is not None:
                 curseg[1].append((op_, o_))
-        steady = next((sg[1] for sg in segs if sg[0].startswith("il_loop") or sg[0].startswith("x4_loop")), None)
+        steady = next((sg[1] for sg in segs if sg[0].startswith("il_loop") or sg[0].startswith("x4_loop") or sg[0].startswith("dq_loop")), None)
         if steady:
             cut = next((k for k, (op_, _) in enumerate(steady) if op_ == "s_branch"), len(steady) - 1) + 1
             finds += ["(back edge) " + f_ for f_ in check(steady[:cut] + steady[:cut], report_from=cut)]
