@@ -40,7 +40,7 @@
   : [q0] "v"(r1f[0]), [q1] "v"(r1f[1]), [q2] "v"(r1f[2]), [q3] "v"(r1f[3]), [q4] "v"(r1f[4]), [q5] "v"(r1f[5]), [q6] "v"(r1f[6]), [q7] "v"(r1f[7]), \
   [d0] "v"(r2f[0]), [d1] "v"(r2f[1]), [d2] "v"(r2f[2]), [d3] "v"(r2f[3]), [d4] "v"(r2f[4]), [d5] "v"(r2f[5]), [d6] "v"(r2f[6]), [d7] "v"(r2f[7]), \
   [kaddr] "v"(a_kaddr), [vat] "v"(a_vat), [ks0] "v"(src[0][0]), [ks1] "v"(src[0][1]), [vs0] "v"(src[1][0]), [vs1] "v"(src[1][1]), \
-  [ts0] "v"(src[2][0]), [ts1] "v"(src[2][1]), [l2] "v"(lse2_lane), [dl] "v"(delta_lane), \
+  [ts0] "v"(src[2][0]), [ts1] "v"(src[2][1]), [l2] "v"(lse2_lane), [dinit] "v"(dinit), \
   [sc] "s"(a_sc), [krs] "s"(rs_fixed[0]), [vrs] "s"(rs_fixed[1]), [ldsw] "s"(a_ldsw), [kstr] "s"(a_kstr), [vstr] "s"(a_vstr), [uend] "s"(a_uend) \
   : "m0", "vcc", "scc", "memory")
 
@@ -354,6 +354,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
     delta_lane = d;
     if (hi == 0 && my_row < p.Nq) p.delta_w[stat_i] = d;
   }
+  // dQ launch, two waves per SIMD: dP starts at -delta of the lane's row instead of 0 — sixteen registers that never change, read as the C operand of each
+  // half's first dP MFMA where it read the inline constant 0 — and dS = P o dP' needs no subtraction per element (32 VALU per tile; every path of the
+  // launch — the hand-scheduled tiles, the compiler-scheduled ones, the windowed instantiation — forms the same sums in the same order)
+  constexpr bool DQ_CINIT = MODE == BWD_DQ && NW == 8;
+  f32x16 dinit;
+  if constexpr (DQ_CINIT) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dinit[r] = -delta_lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(dinit[r]));   // (a register array, not re-materialised per use)
+  }
   // (one wave per SIMD, head dims above 128: the resident fragments live in AccVGPRs — the MFMAs read them there; pinned in
   //  architectural VGPRs hipcc parks them in AccVGPRs anyway and copies four dwords back in front of every MFMA)
 #pragma unroll
@@ -429,7 +440,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
       // ---- GEMM-I: S (and dP) for the 32 tile rows of half t ----------------------------------------------------
       f32x16 s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = DQ_CINIT ? dinit[r] : 0.f; }
       if constexpr (NW == 4) {
         // resident fragments in AccVGPRs, S / dP in VGPRs (Elem::mfma_bacc).  The MFMAs are asm statements, which hipcc keeps in
         // program order and does not pipeline LDS reads around: the fragments are read in groups of eight k-steps, one group ahead.
@@ -510,7 +521,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
         const float l2 = KEYS_RES ? lse2[r] : lse2_lane;
         const float pr = fast_exp2(fmaf(s[r], sc, -l2));
         float y = pr;
-        if (NEED_DP) y = pr * (dp[r] - (KEYS_RES ? dl[r] : delta_lane));
+        if (NEED_DP) y = DQ_CINIT ? pr * dp[r] : pr * (dp[r] - (KEYS_RES ? dl[r] : delta_lane));
         pk[t * 2 + (r >> 3)][r & 7] = (T)y;
       }
       // ---- GEMM-II for the two 16-row slots of this half -----------------------------------------------------------

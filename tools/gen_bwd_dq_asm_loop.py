@@ -7,8 +7,8 @@ waits for it and issues its two MFMAs (matrix pipe 0.42 busy at 2.2 GHz: not the
 
 A tile = 64 keys against the wave's 32 resident query rows, two halves t of 32 keys:
   GI(t)   S_t = K_t Q^T, dP_t = V_t dO^T      16 MFMAs, the two chains alternating; A operands by ds_read_b128 from the row-major K / V images
-  EW(t)   P = exp2(S c - lse2), dS = P (dP - delta), packed IN PLACE (the pair (2k, 2k+1) of 16-key slot s lands in register 8 s + k of S_t: the slot's
-          four registers are GII's B operand without a move): 72 VALU
+  EW(t)   P = exp2(S c - lse2), dS = P dP' (dP' = dP - delta: the dP chain's first MFMA takes -delta of the lane's row as its C operand), packed IN PLACE (the pair (2k, 2k+1) of 16-key slot s lands in register 8 s + k of S_t: the slot's
+          four registers are GII's B operand without a move): 56 VALU
   GII(t)  dQ^T += K_t^T dS_t                   8 MFMAs (two slots x four 32-column blocks), A operands by ds_read_b64_tr_b16 from the transposed K image
 Order in a tile: GI(0) | GI(1) with EW(0) in its shadow | GII(0) with most of EW(1) | GII(1) with the rest — every VALU instruction has an MFMA in front of it.
 Fragments travel as in the forward loop: four 4-register buffers in rotation, requested in pairs two MFMAs ahead, one s_waitcnt per pair.  The tile's first six
@@ -64,7 +64,6 @@ def ew_slots():
         for e in range(16):
             g0 = base + first(e)
             sl[g0].append(f"v_fma_f32 {R(s_, e)}, {R(s_, e)}, %[sc], -%[l2]")
-            sl[g0].append(f"v_sub_f32 {R(p_, e)}, {R(p_, e)}, %[dl]")
             sl[g0 + 1].append(f"v_exp_f32 {R(s_, e)}, {R(s_, e)}")
             sl[g0 + 2].append(f"v_mul_f32 {R(s_, e)}, {R(s_, e)}, {R(p_, e)}")
             if e & 1:
@@ -101,7 +100,8 @@ def body(par):
         if g < 32:
             t, sl, which = g >> 4, (g & 15) >> 1, g & 1
             dst = f"%[{'sp'[which]}{t}]"
-            a(f"{MFMA} {dst}, {frag(g)}, %[{'qd'[which]}{sl}], {'0' if sl == 0 else dst}")
+            c0 = "%[dinit]" if which else "0"               # dP starts at -delta of the lane's row (sixteen registers that never change): no subtraction per element
+            a(f"{MFMA} {dst}, {frag(g)}, %[{'qd'[which]}{sl}], {c0 if sl == 0 else dst}")
         else:
             i = g - 32
             slot, d = i // DT, i % DT                      # 16-key slot 0..3 of the tile, 32-column block of dQ
@@ -160,7 +160,7 @@ def main():
     lb, n = build("bf16")
     lh, _ = build("f16")
     out = ["// tfa_bwd_dq_asm_loop.inc — GENERATED by tools/gen_bwd_dq_asm_loop.py (do not edit; re-generate).  The unmasked tiles of the backward's dQ launch",
-           f"// (bwd_kernel<BWD_DQ>, 128 wide, 8 waves) as hand-scheduled gfx950 assembly: ONE basic block of {n} instructions per 64-key tile (48 MFMA, 144 VALU,",
+           f"// (bwd_kernel<BWD_DQ>, 128 wide, 8 waves) as hand-scheduled gfx950 assembly: ONE basic block of {n} instructions per 64-key tile (48 MFMA, 112 VALU,",
            "// 64 LDS reads, 6 LDS-DMA).  Layout, schedule and the register rules: the generator's docstring."]
     out.extend(emit("TFA_BWD_DQ_ASM_LOOP", lb, n, "bf16"))
     out.extend(emit("TFA_BWD_DQ_ASM_LOOP_F16", lh, n, "fp16"))
