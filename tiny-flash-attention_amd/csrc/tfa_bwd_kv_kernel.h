@@ -18,6 +18,29 @@
 // GQA: the streamed sequence runs over the G query heads of the K/V head, as in tfa_bwd_kernel.h.
 #pragma once
 #include "tfa_bwd_kernel.h"
+#if defined(TFA_BWD_KV_ASM_INC)
+#include TFA_BWD_KV_ASM_INC       // an A/B arm's text (tools/gen_bwd_kv_asm_loop.py with TFA_GEN_KV_* set), never the product build
+#else
+#include "tfa_bwd_kv_asm_loop.inc"
+#endif
+
+#if !defined(TFA_BWD_KV_USE_ASM)
+#define TFA_BWD_KV_USE_ASM 1     // 0: the compiler-scheduled iteration body everywhere (the A/B arm of the hand-scheduled iterations, tools/gen_bwd_kv_asm_loop.py)
+#endif
+// The hand-scheduled unmasked iterations of the fused dK/dV launch: ONE statement for both roles (one register assignment), every operand the compiler's choice.
+#define TFA_BWD_KV_ASM_STMT(TEXT) \
+  asm volatile(TEXT \
+  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [acc3] "+v"(acc[3]), [it] "+s"(a_it), [qoff] "+s"(a_qoff), [doff] "+s"(a_doff), [stoff] "+s"(a_stoff), \
+  [x0] "=&v"(ax0), [x1] "=&v"(ax1), [f0] "=&v"(af0), [f1] "=&v"(af1), [f2] "=&v"(af2), [f3] "=&v"(af3), \
+  [ka] "=&v"(aka), [ka5] "=&v"(aka5), [ka6] "=&v"(aka6), [ka7] "=&v"(aka7), \
+  [t1] "=&v"(at1), [t2] "=&v"(at2), [st] "=&v"(ast), [tm0] "=&v"(atm0), \
+  [pp0] "=&v"(app0), [pp1] "=&v"(app1), [pp2] "=&v"(app2), [pp3] "=&v"(app3) \
+  : [r0] "v"(rf[0]), [r1] "v"(rf[1]), [r2] "v"(rf[2]), [r3] "v"(rf[3]), [r4] "v"(rf[4]), [r5] "v"(rf[5]), [r6] "v"(rf[6]), [r7] "v"(rf[7]), \
+  [kaddr] "v"(a_kaddr), [ta1] "v"(a_ta1), [ta2] "v"(a_ta2), [pxa] "v"(a_pxa), [sta] "v"(a_sta), \
+  [qs0] "v"(src[0][0]), [qs1] "v"(src[0][1]), [ds0] "v"(src[1][0]), [ds1] "v"(src[1][1]), \
+  [sc] "s"(a_sc), [qrs] "s"(q_rs), [drs] "s"(do_rs), [strs] "s"(a_strs), [ldsw] "s"(a_ldsw), [ldsst] "s"(a_ldsst), [qstr] "s"(a_qstr), [dstr] "s"(a_dstr), \
+  [it1] "s"(a_it1), [ph] "s"(a_ph), [role] "s"(a_role), [stq] "s"(a_stq) \
+  : "m0", "vcc", "scc", "memory")
 
 namespace tfa {
 
@@ -50,12 +73,21 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   constexpr int NSTAGE = 3;
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // image 0: Q tile, image 1: dO tile
   constexpr int PX_BYTES = 32 * BN * 2;            // one key group's P tile, 16 bit
+  constexpr int NPX = KG == 4 ? 3 : 2;             // P exchange buffers: one per tile stage (indexed like the stages: the hand-scheduled iterations' three bodies), or by tile parity
+  // the hand-scheduled unmasked iterations (tfa_bwd_kv_asm_loop.inc): the 128-wide eight-wave launch, no workspace, no windows, all four column blocks
+  constexpr bool ASMKV = TFA_BWD_KV_USE_ASM != 0 && D == 128 && KG == 4 && !WS && !BIG && DVB == 4;
   static_assert(PPW >= 1 && PPW * NDMA == PIECES, "");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  char* const pbuf = smem + NSTAGE * STAGE_BYTES;  // [2 parities][KG][PX_BYTES]
-  constexpr int ST_OFF = NSTAGE * STAGE_BYTES + 2 * KG * PX_BYTES;   // per stage: LSE of the tile's 64 query rows (256 B), delta (256 B)
+  // image offsets: stage-major (Q, dO of a stage side by side), or — next to the hand-scheduled iterations — tensor-major (the three Q images, then the three
+  // dO images): every fragment offset of a role then fits the 16-bit immediate of its LDS reads (the role's image base sits in the address registers)
+  auto q_img = [](int stage) -> int { return ASMKV ? stage * TILE_BYTES : stage * STAGE_BYTES; };
+  auto do_img = [](int stage) -> int { return ASMKV ? (NSTAGE + stage) * TILE_BYTES : stage * STAGE_BYTES + TILE_BYTES; };
+  // the resident rows' landing slices (the prologue below): images tile 0 does not use — stages 1 and 2
+  auto slice_off = [](int w) -> int { return ASMKV ? (w < 4 ? TILE_BYTES + w * (32 * D * 2) : (NSTAGE + 1) * TILE_BYTES + (w - 4) * (32 * D * 2)) : STAGE_BYTES + w * (32 * D * 2); };
+  char* const pbuf = smem + NSTAGE * STAGE_BYTES;  // [NPX][KG][PX_BYTES]
+  constexpr int ST_OFF = NSTAGE * STAGE_BYTES + NPX * KG * PX_BYTES;   // per stage: LSE of the tile's 64 query rows (256 B), delta (256 B)
   const char* const sbuf = smem + ST_OFF;
 
 #if defined(TFA_BWD_TRACE)
@@ -145,18 +177,18 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
       const auto qw = rsrc_at(head_base(p.q, g_d), p.q.full, (unsigned long long)jt_d * (unsigned)tile_stride[0]);
       const auto dw = rsrc_at(head_base(p.dout, g_d), p.dout.full, (unsigned long long)jt_d * (unsigned)tile_stride[1]);
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) lds_dma16_m0_fresh(qw, lds_base + stage * STAGE_BYTES + (wave * PPW + i) * 1024, src[0][i]);
+      for (int i = 0; i < PPW; ++i) lds_dma16_m0_fresh(qw, lds_base + q_img(stage) + (wave * PPW + i) * 1024, src[0][i]);
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) lds_dma16_m0_fresh(dw, lds_base + stage * STAGE_BYTES + TILE_BYTES + (wave * PPW + i) * 1024, src[1][i]);
+      for (int i = 0; i < PPW; ++i) lds_dma16_m0_fresh(dw, lds_base + do_img(stage) + (wave * PPW + i) * 1024, src[1][i]);
       if (++jt_d == t_end) { jt_d = t_begin; if (++g_d < G) { lse_rs = stat_rsrc(p.lse, g_d); dl_rs = stat_rsrc(p.delta, g_d); } }
       return;
     }
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
-      lds_dma16_m0(q_rs, lds_base + stage * STAGE_BYTES + (wave * PPW + i) * 1024, src[0][i] + jt_d * tile_stride[0]);
+      lds_dma16_m0(q_rs, lds_base + q_img(stage) + (wave * PPW + i) * 1024, src[0][i] + jt_d * tile_stride[0]);
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
-      lds_dma16_m0(do_rs, lds_base + stage * STAGE_BYTES + TILE_BYTES + (wave * PPW + i) * 1024, src[1][i] + jt_d * tile_stride[1]);
+      lds_dma16_m0(do_rs, lds_base + do_img(stage) + (wave * PPW + i) * 1024, src[1][i] + jt_d * tile_stride[1]);
     if (++jt_d == t_end) {
       jt_d = t_begin;
       if (++g_d < G) { q_rs = head_rsrc(p.q, g_d); do_rs = head_rsrc(p.dout, g_d); lse_rs = stat_rsrc(p.lse, g_d); dl_rs = stat_rsrc(p.delta, g_d); }
@@ -174,7 +206,7 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
       // instead of 256 32-byte segments — in its slice of stages 1 and 2 (idle until iteration 0 requests tile 1, behind the barrier below),
       // chunk position XOR u_swz(row); the fragments are read back once tile 0 has been requested
       constexpr int RPP = 1024 / (D * 2);            // rows per piece
-      const unsigned slice = __builtin_amdgcn_readfirstlane(lds_base + STAGE_BYTES + wave * (32 * D * 2));
+      const unsigned slice = __builtin_amdgcn_readfirstlane(lds_base + slice_off(wave));
       int lanex = lane;                              // (through an empty asm: this one-off address math shares nothing with the tile loop's)
       asm volatile("" : "+v"(lanex));
 #pragma unroll
@@ -235,7 +267,7 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   if (nu > 0) dma_next(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (KG == 4) {
-    const char* const sl = smem + STAGE_BYTES + wave * (32 * D * 2);
+    const char* const sl = smem + slice_off(wave);
     int qix = qi, hix = hi;
     asm volatile("" : "+v"(qix), "+v"(hix));
 #pragma unroll
@@ -262,23 +294,73 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
     const float v0 = (role == 0 && my_row >= p.Nk) ? -INFINITY : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) xinit[r] = v0;
+    // (keep it a register array, not re-materialised per use — except next to the hand-scheduled iterations, which need the sixteen registers and leave
+    //  the compiler-scheduled body a handful of iterations: there it is one register, copied per half)
+    if constexpr (!ASMKV) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(xinit[r]));   // (keep it a register array: not re-materialised per use)
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(xinit[r]));
+    }
   }
   int st_next = 1;                                   // stage of tile it+1
   int st_mine = role ? NSTAGE - 1 : 0;               // stage of this wave's tile (role 1: tile it-1)
+  // ---- the hand-scheduled iterations a_it0 .. a_it1 - 1 of this wave: its tile (role 0: it, role 1: it - 1) needs no mask, tile it + 1 exists and lies wholly
+  //      inside the query rows (its LDS-DMA pieces take the tile's byte offset as the SCALAR offset, outside the descriptor's bounds check), one streamed head
+  //      (G = 1), every key of the block inside the sequence (the -inf start of a padded key's S is the compiler-scheduled body's)
+  int a_it0 = 0, a_it1 = 0;
+  if constexpr (ASMKV) {
+    if (G == 1 && r0 + BMK <= p.Nk) {
+      int um = 0;
+      if (CAUSAL) {
+        const int v = wave_row0 + 31 - shift;
+        const int jm = v > 0 ? (v + BN - 1) / BN : 0;  // first tile whose 64 queries all see the wave's 32 keys
+        um = jm > t_begin ? jm - t_begin : 0;
+      }
+      a_it0 = um + role;
+      a_it1 = nu - 1;
+      { const int whole = p.Nq / BN - t_begin - 1; a_it1 = whole < a_it1 ? whole : a_it1; }
+    }
+    a_it0 = __builtin_amdgcn_readfirstlane(a_it0);
+    a_it1 = __builtin_amdgcn_readfirstlane(a_it1);
+  }
 #pragma nounroll
   for (int it = 0; it <= nu; ++it) {
+    if constexpr (ASMKV) {
+      if (it == a_it0 && a_it1 > a_it0) {
+        f32x16 ax0, ax1, ast;
+        u32x4 af0, af1, af2, af3, aka, at1, at2, app0, app1, app2, app3, atm0;
+        unsigned aka5, aka6, aka7;
+        // (the role's images: GEMM-I reads rows of Q (role 0) / dO (role 1), GEMM-II the transposed dO (role 0) / Q (role 1))
+        const unsigned a_kaddr = lds_base + (role ? do_img(0) : q_img(0)) + (unsigned)k_rd_base + ((unsigned)(hi ^ k_rd_swz) << 4);
+        const unsigned a_ta1 = lds_base + (role ? q_img(0) : do_img(0)) + (unsigned)tr_b1 + ((unsigned)(tr_clo ^ tr_s1) << 4);
+        const unsigned a_ta2 = lds_base + (role ? q_img(0) : do_img(0)) + (unsigned)tr_b2 + ((unsigned)(tr_clo ^ tr_s2) << 4);
+        const unsigned a_pxa = lds_base + NSTAGE * STAGE_BYTES + kg * PX_BYTES + lane * 16;
+        const unsigned a_sta = lds_base + ST_OFF + role * 256 + hi * 16;
+        const unsigned a_ldsw = __builtin_amdgcn_readfirstlane(lds_base + wave * (PPW * 1024));
+        const unsigned a_ldsst = __builtin_amdgcn_readfirstlane(lds_base + ST_OFF + (wave & 1) * 256);
+        const int a_qstr = __builtin_amdgcn_readfirstlane(tile_stride[0]), a_dstr = __builtin_amdgcn_readfirstlane(tile_stride[1]);
+        const float a_sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc)));
+        const int a_role = __builtin_amdgcn_readfirstlane(role), a_stq = __builtin_amdgcn_readfirstlane(wave < 2 ? 1 : 0), a_ph = __builtin_amdgcn_readfirstlane(it % 3);
+        const auto a_strs = wave ? dl_rs : lse_rs;
+        int a_it = it, a_qoff = __builtin_amdgcn_readfirstlane(jt_d * tile_stride[0]), a_doff = __builtin_amdgcn_readfirstlane(jt_d * tile_stride[1]);
+        int a_stoff = __builtin_amdgcn_readfirstlane(jt_d * (BN * 4));
+        if constexpr (std::is_same<T, __bf16>::value) { TFA_BWD_KV_ASM_STMT(TFA_BWD_KV_ASM_LOOP); }
+        else { TFA_BWD_KV_ASM_STMT(TFA_BWD_KV_ASM_LOOP_F16); }
+        const int n = a_it - it;                       // iterations done: the streams' positions and the stage rotation move with them
+        jt_d += n; jt_c += n;
+        st_next = (st_next + n) % NSTAGE; st_mine = (st_mine + n) % NSTAGE;
+        it = a_it;
+      }
+    }
     if (it + 1 < nu) dma_next(st_next);              // tile it+1; that stage held tile it-2: role 1 left it at the last barrier
     const int u = it - role;
     if (u >= 0 && u < nu) {
       const int g = g_c, jt = jt_c;
       const int row0 = jt * BN;                      // first query row of the tile
-      const char* img_q = smem + st_mine * STAGE_BYTES;
-      const char* img_do = img_q + TILE_BYTES;
+      const char* img_q = smem + q_img(st_mine);
+      const char* img_do = smem + do_img(st_mine);
       const char* img1 = role ? img_do : img_q;      // GEMM-I operand rows (role 0: Q, role 1: dO)
       const char* imgt = role ? img_q : img_do;      // GEMM-II transposed operand (role 0: dO, role 1: Q)
-      char* const px = pbuf + ((u & 1) * KG + kg) * PX_BYTES;
+      char* const px = pbuf + ((NPX == 3 ? st_mine : (u & 1)) * KG + kg) * PX_BYTES;
 
       // this wave's 32 keys x 64 queries: anything masked?  everything masked?
       const bool need_mask = CAUSAL && (row0 < wave_row0 + 31 - shift);
@@ -296,6 +378,16 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
         stored = true;
       }
       if (active) {
+        // (next to the hand-scheduled iterations the fragment-address pieces are re-derived HERE from the lane id, behind an empty asm: a dozen loop-invariant
+        //  registers that would otherwise stay live across the statement, which needs them for its own operands; the other instantiations hoist them as before)
+        int lane_l = lane;
+        if constexpr (ASMKV) asm volatile("" : "+v"(lane_l));
+        const int qi_l = lane_l & 31, hi_l = lane_l >> 5;
+        const int k_rd_base = qi_l * (D * 2), k_rd_swz = u_swz<D>(qi_l);
+        const int i16_l = lane_l & 15, g16_l = (lane_l >> 4) & 1;
+        const int tr_row = 4 * hi_l + (i16_l >> 2), tr_clo = 2 * g16_l + ((i16_l & 3) >> 1), tr_byte = ((i16_l & 3) & 1) * 8;
+        const int tr_s1 = u_swz<D>(tr_row), tr_s2 = u_swz<D>(tr_row + 8);
+        const int tr_b1 = tr_row * (D * 2) + tr_byte, tr_b2 = (tr_row + 8) * (D * 2) + tr_byte;
         // statistics of the 64 tile rows first (both halves): no load is issued between the dS stores below and the barrier
         // statistics of the tile's rows from the stage's LDS copy: this lane's 16 rows of half t are 4 runs of 4 consecutive rows
         float stv[2][16];

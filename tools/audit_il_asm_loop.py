@@ -2,7 +2,7 @@
 """Static audit of the hand-scheduled tile loop (tfa_fwd_il_asm_loop.inc) on the DISASSEMBLED object — registers resolved, unlike the .s file, whose asm
 text still carries the assembler symbols.  usage: audit_il_asm_loop.py file.o [kernel-name substring]   (exit status 1 on any finding)
 
-Finds the statement (between its own labels: il_loop<N> .. il_exit<N>, ix_b.. .. ix_exit<N>, x4_loop<N> .. x4_exit<N>, dq_loop<N> .. dq_exit<N>) in every kernel that has one and
+Finds the statement (between its own labels: il_loop<N> .. il_exit<N>, ix_b.. .. ix_exit<N>, x4_loop<N> .. x4_exit<N>, dq_loop<N> .. dq_exit<N>, kv_r0b0<N> .. kv_exit<N>) in every kernel that has one and
 checks, over the linear instruction sequence, over the steady-state bodies once more behind themselves (the back edge) and over every pair of exact bodies:
   1. every LDS-read destination is complete (s_waitcnt lgkmcnt, LDS returns in order) before an instruction reads it;
   2. a VALU write of an MFMA A/B/C operand is >= 2 instructions in front of the MFMA;
@@ -97,6 +97,12 @@ def check(loop, report_from=0):
             pending.append(dst)
             inflight.update(dst)
             continue
+        if op.startswith("ds_write"):                  # (a store holds its place in the in-order LDS queue that lgkmcnt counts; it has no destination)
+            for r in [x for o_ in ops for x in regs(o_)]:
+                if r in inflight:
+                    say(idx, f"   [1] {op} reads v{r} while its LDS read is in flight (#{idx})")
+            pending.append([])
+            continue
         if op.startswith("buffer_load"):
             srcs = regs(ops[0])
             dst = []
@@ -155,8 +161,8 @@ def main():
             continue
         # the loop lies between the asm statement's own labels: il_loop<N> .. il_exit<N> (lazy reference), the first ix_b.. label's exact_step .. ix_exit<N>
         labels = [(i, o[0]) for i, (op, o) in enumerate(ins) if op == "label"]
-        first = next((i for i, n in labels if n.startswith("il_loop") or n.startswith("ix_b") or n.startswith("x4_loop") or n.startswith("dq_loop")), None)
-        last = next((i for i, n in labels if n.startswith("il_exit") or n.startswith("ix_exit") or n.startswith("x4_exit") or n.startswith("dq_exit")), None)
+        first = next((i for i, n in labels if n.startswith("il_loop") or n.startswith("ix_b") or n.startswith("x4_loop") or n.startswith("dq_loop") or n.startswith("kv_r0b0")), None)
+        last = next((i for i, n in labels if n.startswith("il_exit") or n.startswith("ix_exit") or n.startswith("x4_exit") or n.startswith("dq_exit") or n.startswith("kv_exit")), None)
         if first is None or last is None:
             continue
         if any(n.startswith("ix_b") for _, n in labels):
@@ -189,6 +195,25 @@ def main():
         for a_ in xb:
             for b_ in xb:
                 finds += ["(body pair) " + f_ for f_ in check(a_ + b_, report_from=len(a_))]
+        # the fused dK/dV statement: per role three bodies in rotation (kv_r<role>b<phase>; the labels in between — a skipped request — split nothing)
+        for role in "01":
+            kb = []
+            for ph in "012":
+                body, on = [], False
+                for sg in segs:
+                    if sg[0].startswith(f"kv_r{role}b{ph}") and not sg[0].startswith(f"kv_r{role}b{ph}ns"):
+                        on = True
+                    elif on and sg[0].startswith("kv_r") and not sg[0].startswith(f"kv_r{role}b{ph}ns"):
+                        on = False
+                    elif on and sg[0].startswith("kv_exit"):
+                        on = False
+                    if on:
+                        body += sg[1]
+                kb.append(body)
+            if all(kb):
+                for i_ in range(3):
+                    a_, b_ = kb[i_], kb[(i_ + 1) % 3]
+                    finds += [f"(role {role} phase {i_} -> {(i_ + 1) % 3}) " + f_ for f_ in check(a_ + b_, report_from=len(a_))]
         for f_ in finds:
             print(f_)
         bad += len(finds)
