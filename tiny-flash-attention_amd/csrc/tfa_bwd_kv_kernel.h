@@ -30,7 +30,7 @@
 // The hand-scheduled unmasked iterations of the fused dK/dV launch: ONE statement for both roles (one register assignment), every operand the compiler's choice.
 #define TFA_BWD_KV_ASM_STMT(TEXT) \
   asm volatile(TEXT \
-  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [acc3] "+v"(acc[3]), [it] "+s"(a_it), [qoff] "+s"(a_qoff), [doff] "+s"(a_doff), [stoff] "+s"(a_stoff), \
+  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [acc3] "+v"(acc[3]), [it] "+s"(a_it), [qoff] "+s"(a_qoff), [doff] "+s"(a_doff), [stoff] "+s"(a_stoff), [lim] "+v"(a_lim), [ts] "=&s"(a_ts), [msk] "=&s"(a_msk), [ninf] "=&v"(a_ninf), \
   [x0] "=&v"(ax0), [x1] "=&v"(ax1), [f0] "=&v"(af0), [f1] "=&v"(af1), [f2] "=&v"(af2), [f3] "=&v"(af3), \
   [ka] "=&v"(aka), [ka5] "=&v"(aka5), [ka6] "=&v"(aka6), [ka7] "=&v"(aka7), \
   [t1] "=&v"(at1), [t2] "=&v"(at2), [st] "=&v"(ast), [tm0] "=&v"(atm0), \
@@ -39,7 +39,7 @@
   [kaddr] "v"(a_kaddr), [ta1] "v"(a_ta1), [ta2] "v"(a_ta2), [pxa] "v"(a_pxa), [sta] "v"(a_sta), \
   [qs0] "v"(src[0][0]), [qs1] "v"(src[0][1]), [ds0] "v"(src[1][0]), [ds1] "v"(src[1][1]), \
   [sc] "s"(a_sc), [qrs] "s"(q_rs), [drs] "s"(do_rs), [strs] "s"(a_strs), [ldsw] "s"(a_ldsw), [ldsst] "s"(a_ldsst), [qstr] "s"(a_qstr), [dstr] "s"(a_dstr), \
-  [it1] "s"(a_it1), [ph] "s"(a_ph), [role] "s"(a_role), [stq] "s"(a_stq) \
+  [it1] "s"(a_it1), [ph] "s"(a_ph), [role] "s"(a_role), [stq] "s"(a_stq), [nu] "s"(a_nu), [um] "s"(a_um) \
   : "m0", "vcc", "scc", "memory")
 
 namespace tfa {
@@ -306,21 +306,26 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   // ---- the hand-scheduled iterations a_it0 .. a_it1 - 1 of this wave: its tile (role 0: it, role 1: it - 1) needs no mask, tile it + 1 exists and lies wholly
   //      inside the query rows (its LDS-DMA pieces take the tile's byte offset as the SCALAR offset, outside the descriptor's bounds check), one streamed head
   //      (G = 1), every key of the block inside the sequence (the -inf start of a padded key's S is the compiler-scheduled body's)
-  int a_it0 = 0, a_it1 = 0;
+  int a_it0 = 0, a_it1 = 0, a_um = 0;
   if constexpr (ASMKV) {
     if (G == 1 && r0 + BMK <= p.Nk) {
-      int um = 0;
+      int ua = 0, um = 0;                              // the wave's first active tile / first tile without a mask (positions in the block's tile sequence)
       if (CAUSAL) {
-        const int v = wave_row0 + 31 - shift;
-        const int jm = v > 0 ? (v + BN - 1) / BN : 0;  // first tile whose 64 queries all see the wave's 32 keys
+        const int v = wave_row0 - shift;               // the first query that sees the wave's first key
+        const int ja = v > 0 ? v / BN : 0;             // first tile with a query that sees a key of the wave
+        const int jm = v + 31 > 0 ? (v + 31 + BN - 1) / BN : 0;   // first tile whose 64 queries all see the wave's 32 keys
+        ua = ja > t_begin ? ja - t_begin : 0;
         um = jm > t_begin ? jm - t_begin : 0;
       }
-      a_it0 = um + role;
-      a_it1 = nu - 1;
-      { const int whole = p.Nq / BN - t_begin - 1; a_it1 = whole < a_it1 ? whole : a_it1; }
+      a_it0 = ua + role;                               // role 0: masked tiles too (its masked bodies); role 1 needs none (P arrives masked)
+      a_um = um;
+      // every tile requested from inside the statement lies wholly inside the query rows: all of them when the last tile is whole, else up to the last but one
+      if (p.Nq % BN == 0) a_it1 = nu + role;
+      else { a_it1 = nu - 1; const int whole = p.Nq / BN - t_begin - 1; a_it1 = whole < a_it1 ? whole : a_it1; }
     }
     a_it0 = __builtin_amdgcn_readfirstlane(a_it0);
     a_it1 = __builtin_amdgcn_readfirstlane(a_it1);
+    a_um = __builtin_amdgcn_readfirstlane(a_um);
   }
 #pragma nounroll
   for (int it = 0; it <= nu; ++it) {
@@ -343,12 +348,18 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
         const auto a_strs = wave ? dl_rs : lse_rs;
         int a_it = it, a_qoff = __builtin_amdgcn_readfirstlane(jt_d * tile_stride[0]), a_doff = __builtin_amdgcn_readfirstlane(jt_d * tile_stride[1]);
         int a_stoff = __builtin_amdgcn_readfirstlane(jt_d * (BN * 4));
+        const int a_nu = __builtin_amdgcn_readfirstlane(nu);
+        int a_lim = my_row - shift - jt_c * BN - 4 * hi;   // role 0's masked bodies: queries of the tile below this offset do not see the lane's key
+        int a_ts;
+        unsigned long long a_msk;
+        float a_ninf;
         if constexpr (std::is_same<T, __bf16>::value) { TFA_BWD_KV_ASM_STMT(TFA_BWD_KV_ASM_LOOP); }
         else { TFA_BWD_KV_ASM_STMT(TFA_BWD_KV_ASM_LOOP_F16); }
         const int n = a_it - it;                       // iterations done: the streams' positions and the stage rotation move with them
         jt_d += n; jt_c += n;
         st_next = (st_next + n) % NSTAGE; st_mine = (st_mine + n) % NSTAGE;
         it = a_it;
+        if (it > nu) break;                            // (role 1 ran the last iteration inside the statement)
       }
     }
     if (it + 1 < nu) dma_next(st_next);              // tile it+1; that stage held tile it-2: role 1 left it at the last barrier

@@ -161,7 +161,7 @@ def main():
             continue
         # the loop lies between the asm statement's own labels: il_loop<N> .. il_exit<N> (lazy reference), the first ix_b.. label's exact_step .. ix_exit<N>
         labels = [(i, o[0]) for i, (op, o) in enumerate(ins) if op == "label"]
-        first = next((i for i, n in labels if n.startswith("il_loop") or n.startswith("ix_b") or n.startswith("x4_loop") or n.startswith("dq_loop") or n.startswith("kv_r0b0")), None)
+        first = next((i for i, n in labels if n.startswith("il_loop") or n.startswith("ix_b") or n.startswith("x4_loop") or n.startswith("dq_loop") or n.startswith("kv_r0")), None)
         last = next((i for i, n in labels if n.startswith("il_exit") or n.startswith("ix_exit") or n.startswith("x4_exit") or n.startswith("dq_exit") or n.startswith("kv_exit")), None)
         if first is None or last is None:
             continue
@@ -201,9 +201,9 @@ def main():
             for ph in "012":
                 body, on = [], False
                 for sg in segs:
-                    if sg[0].startswith(f"kv_r{role}b{ph}") and not sg[0].startswith(f"kv_r{role}b{ph}ns"):
+                    if sg[0].startswith(f"kv_r{role}b{ph}") and not sg[0].startswith(f"kv_r{role}b{ph}n"):
                         on = True
-                    elif on and sg[0].startswith("kv_r") and not sg[0].startswith(f"kv_r{role}b{ph}ns"):
+                    elif on and sg[0].startswith("kv_r") and not sg[0].startswith(f"kv_r{role}b{ph}n"):
                         on = False
                     elif on and sg[0].startswith("kv_exit"):
                         on = False

@@ -78,7 +78,7 @@ def frag_reads(g, role, st):
     return [f"ds_read_b64_tr_b16 v[F{b}+0:F{b}+1], v[T1+{d}] offset:{off}", f"ds_read_b64_tr_b16 v[F{b}+2:F{b}+3], v[T2+{d}] offset:{off}"]
 
 
-def ew_plan(role):
+def ew_plan(role, mask=False):
     """slot -> the element-wise work of both halves behind the MFMAs.  Three steps per element: A (the only reader of the row statistics: scale + subtract, or
     subtract) early — the sixteen statistics registers serve both halves, half 1's are read once half 0's step A is through —, B (exp2 / the 16-bit P unpacked
     into one of eight rotating temporaries) and C (the product; the pack of a pair, the P hand-off of a complete slot) spread over the slots up to their MFMA"""
@@ -91,6 +91,10 @@ def ew_plan(role):
             gA = (9 if t == 0 else 17) + e // 4
             assert gA <= g0
             if role == 0:
+                if mask:                                   # query offset qo of element e inside the tile; the lane's key is hidden from queries below %[lim]
+                    qo = 32 * t + (e & 3) + 8 * (e >> 2)
+                    sl[gA].append(f"v_cmp_ge_i32 %[msk], {qo}, %[lim]")
+                    sl[gA].append(f"v_cndmask_b32 {R(X, e)}, %[ninf], {R(X, e)}, %[msk]")
                 sl[gA].append(f"v_mul_f32 {R('ST', e)}, 0x3fb8aa3b, {R('ST', e)}")
                 sl[gA].append(f"v_fma_f32 {R(X, e)}, {R(X, e)}, %[sc], -{R('ST', e)}")
                 sl[g0 + 1].append(f"v_exp_f32 {R(X, e)}, {R(X, e)}")
@@ -120,15 +124,21 @@ def ew_plan(role):
     return sl
 
 
-def body(role, b):
-    """iteration body of phase b = it mod 3"""
+def body(role, b, mask=False):
+    """iteration body of phase b = it mod 3.  mask (role 0): the wave's diagonal tiles — S is set to -inf where the query lies before the lane's key (two VALU per
+    element in front of its scale / subtract; the compare result in an SGPR pair: vcc carries the tile's "tile it + 1 exists" flag for the LDS-DMA pieces)"""
     o = []
     a = o.append
     st = b if role == 0 else (b + 2) % 3                   # stage (and P buffer) of this wave's tile
     sn = (b + 1) % 3                                       # stage of tile it + 1: the DMA's target
     a(f"; ---- role {role}, phase {b}: tile in stage {st}, requests into stage {sn}")
     q = Q(o)
-    ew = ew_plan(role)
+    ew = ew_plan(role, mask)
+    tag = f"kv_r{role}{'m' if mask else 'b'}{b}"
+    # the last iterations request nothing (tile it + 1 does not exist): vcc = (it + 1 < nu), every request branches on it
+    a("s_add_u32 %[ts], %[it], 1")
+    a("s_cmp_lt_i32 %[ts], %[nu]")
+    a("s_cselect_b64 vcc, -1, 0")
     dma = [((3 * img + sn) * 0x4000 + i * 1024, f"%[{'qd'[img]}s{i}]", f"%[{'qd'[img]}rs]", f"%[{'qd'[img]}off]") for img in (0, 1) for i in (0, 1)]
     for k in (0, 1):
         for l in frag_reads(k, role, st):
@@ -156,7 +166,9 @@ def body(role, b):
             for l in frag_reads(g + 3, role, st):
                 q.push(("f", g + 3), l)
         if g < len(dma) and "nodma" not in ABL:
+            a(f"s_cbranch_vccz {tag}nd{g}%=")
             a(f"buffer_load_dwordx4 {dma[g][1]}, {dma[g][2]}, {dma[g][3]} offen lds")
+            a(f"{tag}nd{g}%=:")
         if g in (1, 13):
             # the tile's row statistics (this lane's 16 rows of a half: four runs of four): half 0's behind the second MFMA, half 1's once half 0's were used
             t = 0 if g == 1 else 1
@@ -169,14 +181,15 @@ def body(role, b):
         if g == 4 and role == 0:
             # waves 0 and 1 also fetch the statistics of tile it + 1 (LSE / delta: one dword per lane)
             a("s_cmp_eq_u32 %[stq], 0")
-            a(f"s_cbranch_scc1 kv_r{role}b{b}ns%=")
+            a(f"s_cbranch_scc1 {tag}ns%=")
+            a(f"s_cbranch_vccz {tag}ns%=")
             a(f"s_add_u32 m0, %[ldsst], {sn * 512}")
             a("s_nop 0")
             a("v_mbcnt_lo_u32_b32 v[TM0+0], -1, 0")        # (lane * 4, in a temporary that is idle this early in the tile)
             a("v_mbcnt_hi_u32_b32 v[TM0+0], -1, v[TM0+0]")
             a("v_lshlrev_b32 v[TM0+0], 2, v[TM0+0]")
             a("buffer_load_dword v[TM0+0], %[strs], %[stoff] offen lds")
-            a(f"kv_r{role}b{b}ns%=:")
+            a(f"{tag}ns%=:")
         for item in ew[g]:
             if "novalu" in ABL:
                 continue
@@ -199,8 +212,14 @@ def body(role, b):
     a("s_add_u32 %[qoff], %[qoff], %[qstr]")
     a("s_add_u32 %[doff], %[doff], %[dstr]")
     a("s_add_u32 %[stoff], %[stoff], 256")
+    if mask:
+        a("v_subrev_u32 %[lim], 64, %[lim]")               # the next tile's queries are 64 further on
     a("s_cmp_ge_i32 %[it], %[it1]")
     a("s_cbranch_scc1 kv_exit%=")
+    if mask:                                               # on to the next phase: its masked body while the wave's tiles still cross the diagonal
+        a("s_cmp_ge_i32 %[it], %[um]")
+        a(f"s_cbranch_scc1 kv_r0b{(b + 1) % 3}%=")
+        a(f"s_branch kv_r0m{(b + 1) % 3}%=")
     return o
 
 
@@ -218,11 +237,23 @@ def build(dtype):
     for d in range(DT):
         a(f"v_xor_b32 v[T1+{d}], {d << 6}, %[ta1]")
         a(f"v_xor_b32 v[T2+{d}], {d << 6}, %[ta2]")
+    a("v_mov_b32 %[ninf], 0xff800000")
     a("s_cmp_eq_u32 %[role], 1")
     a("s_cbranch_scc1 kv_r1%=")
     for role in (0, 1):
         if role:
             a("kv_r1%=:")
+        else:                                              # role 0 starts in its masked bodies while it < um
+            a("s_cmp_ge_i32 %[it], %[um]")
+            a("s_cbranch_scc1 kv_r0u%=")
+            a("s_cmp_eq_u32 %[ph], 1")
+            a("s_cbranch_scc1 kv_r0m1%=")
+            a("s_cmp_eq_u32 %[ph], 2")
+            a("s_cbranch_scc1 kv_r0m2%=")
+            for b in range(3):
+                a(f"kv_r0m{b}%=:")
+                lines.extend(body(0, b, mask=True))
+            a("kv_r0u%=:")
         a("s_cmp_eq_u32 %[ph], 1")
         a(f"s_cbranch_scc1 kv_r{role}b1%=")
         a("s_cmp_eq_u32 %[ph], 2")
