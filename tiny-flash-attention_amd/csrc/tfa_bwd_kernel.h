@@ -34,14 +34,14 @@
 // The hand-scheduled unmasked tiles of the dQ launch: ONE statement (one register assignment), every operand the compiler's choice.
 #define TFA_BWD_DQ_ASM_STMT(TEXT) \
   asm volatile(TEXT \
-  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [acc3] "+v"(acc[3]), [u] "+s"(ua), [koff] "+s"(koff), [voff] "+s"(voff), \
+  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [acc3] "+v"(acc[3]), [u] "+s"(ua), [koff] "+s"(koff), [voff] "+s"(voff), [lim] "+v"(a_lim), [ts] "=&s"(a_ts), [msk] "=&s"(a_msk), [ninf] "=&v"(a_ninf), \
   [s0] "=&v"(as0), [p0] "=&v"(ap0), [s1] "=&v"(as1), [p1] "=&v"(ap1), [f0] "=&v"(af0), [f1] "=&v"(af1), [f2] "=&v"(af2), [f3] "=&v"(af3), \
   [ka] "=&v"(aka), [ka5] "=&v"(aka5), [ka6] "=&v"(aka6), [ka7] "=&v"(aka7) \
   : [q0] "v"(r1f[0]), [q1] "v"(r1f[1]), [q2] "v"(r1f[2]), [q3] "v"(r1f[3]), [q4] "v"(r1f[4]), [q5] "v"(r1f[5]), [q6] "v"(r1f[6]), [q7] "v"(r1f[7]), \
   [d0] "v"(r2f[0]), [d1] "v"(r2f[1]), [d2] "v"(r2f[2]), [d3] "v"(r2f[3]), [d4] "v"(r2f[4]), [d5] "v"(r2f[5]), [d6] "v"(r2f[6]), [d7] "v"(r2f[7]), \
   [kaddr] "v"(a_kaddr), [vat] "v"(a_vat), [ks0] "v"(src[0][0]), [ks1] "v"(src[0][1]), [vs0] "v"(src[1][0]), [vs1] "v"(src[1][1]), \
   [ts0] "v"(src[2][0]), [ts1] "v"(src[2][1]), [l2] "v"(lse2_lane), [dinit] "v"(dinit), \
-  [sc] "s"(a_sc), [krs] "s"(rs_fixed[0]), [vrs] "s"(rs_fixed[1]), [ldsw] "s"(a_ldsw), [kstr] "s"(a_kstr), [vstr] "s"(a_vstr), [uend] "s"(a_uend) \
+  [sc] "s"(a_sc), [krs] "s"(rs_fixed[0]), [vrs] "s"(rs_fixed[1]), [ldsw] "s"(a_ldsw), [kstr] "s"(a_kstr), [vstr] "s"(a_vstr), [uend] "s"(a_uend), [mend] "s"(a_mend), [nu] "s"(a_nu) \
   : "m0", "vcc", "scc", "memory")
 
 namespace tfa {
@@ -383,15 +383,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
   //      byte offset as the SCALAR offset, which the descriptor's bounds check ignores); the loop below takes over at tile u0 with the same stage / barrier protocol
   int u0 = 0;
   if constexpr (ASMDQ) {
-    int a_uend = nu - 1;
-    { const int whole = p.Nk / BN - 1; a_uend = whole < a_uend ? whole : a_uend; }
+    // tiles 0 .. a_uend - 1 need no mask, a_uend .. a_mend - 1 are the wave's diagonal tiles (its masked bodies); every tile worked on or requested inside the
+    // statement lies wholly inside the keys: all of the block's when the last one is whole, else up to the last but one
+    int lim_t = nu;
+    if (p.Nk % BN != 0) { lim_t = nu - 1; const int whole = p.Nk / BN - 1; lim_t = whole < lim_t ? whole : lim_t; }
+    int a_uend = lim_t, a_mend = lim_t;
     if (CAUSAL) {
-      const int d = wave_row0 + shift - (BN - 1);            // last key of tile u <= the wave's first row's limit: u <= d / 64
-      const int lim = d >= 0 ? d / BN + 1 : 0;
-      a_uend = lim < a_uend ? lim : a_uend;
+      const int d = wave_row0 + shift - (BN - 1);            // last key of tile u <= the limit of the wave's first row: u <= d / 64
+      const int nun = d >= 0 ? d / BN + 1 : 0;
+      const int e = wave_row0 + 31 + shift;                  // first key of tile u <= the limit of the wave's last row: u <= e / 64
+      const int nac = e >= 0 ? e / BN + 1 : 0;
+      a_uend = nun < a_uend ? nun : a_uend;
+      a_mend = nac < a_mend ? nac : a_mend;
     }
     a_uend = __builtin_amdgcn_readfirstlane(a_uend);
-    if (a_uend > 0) {
+    a_mend = __builtin_amdgcn_readfirstlane(a_mend);
+    if (a_mend > 0) {
       f32x16 as0, ap0, as1, ap1;
       u32x4 af0, af1, af2, af3, aka;
       unsigned aka5, aka6, aka7;
@@ -400,6 +407,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
       const unsigned a_ldsw = __builtin_amdgcn_readfirstlane(lds_base + wave * (PPW * 1024));
       const int a_kstr = __builtin_amdgcn_readfirstlane(tile_stride[0]), a_vstr = __builtin_amdgcn_readfirstlane(tile_stride[1]);
       const float a_sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc)));
+      const int a_nu = __builtin_amdgcn_readfirstlane(nu);
+      int a_lim = my_row + shift - a_uend * BN - 4 * hi;     // the masked bodies: keys of the tile beyond this offset lie behind the lane's row
+      int a_ts;
+      unsigned long long a_msk;
+      float a_ninf;
       int ua = 0, koff = a_kstr, voff = a_vstr;
       if constexpr (std::is_same<T, __bf16>::value) { TFA_BWD_DQ_ASM_STMT(TFA_BWD_DQ_ASM_LOOP); }
       else { TFA_BWD_DQ_ASM_STMT(TFA_BWD_DQ_ASM_LOOP_F16); }

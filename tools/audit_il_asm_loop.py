@@ -187,7 +187,15 @@ def main():
                 segs.append(curseg)
             elif curseg is not None:
                 curseg[1].append((op_, o_))
-        steady = next((sg[1] for sg in segs if sg[0].startswith("il_loop") or sg[0].startswith("x4_loop") or sg[0].startswith("dq_loop")), None)
+        steady = None
+        for k_, sg in enumerate(segs):
+            if sg[0].startswith("il_loop") or sg[0].startswith("x4_loop") or sg[0].startswith("dq_loop"):
+                steady = list(sg[1])
+                for sg2 in segs[k_ + 1:]:                  # (the dQ bodies carry labels of their own — a skipped request — that split nothing)
+                    if not sg2[0].startswith("dq_b"):
+                        break
+                    steady += sg2[1]
+                break
         if steady:
             cut = next((k for k, (op_, _) in enumerate(steady) if op_ == "s_branch"), len(steady) - 1) + 1
             finds += ["(back edge) " + f_ for f_ in check(steady[:cut] + steady[:cut], report_from=cut)]

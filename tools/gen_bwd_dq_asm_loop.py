@@ -56,13 +56,17 @@ def R(sym, e, n=1):
     return f"v[{sym}+{e}]" if n == 1 else f"v[{sym}+{e}:{sym}+{e + n - 1}]"
 
 
-def ew_slots():
+def ew_slots(mask=False):
     """slot (MFMA index of the tile) -> element-wise instructions issued behind that MFMA"""
     sl = {g: [] for g in range(NG)}
     for t, (base, first) in enumerate(((16, lambda e: 1 + e * 13 // 16), (32, lambda e: (1 + e * 4 // 8) if e < 8 else (3 + (e - 8) * 6 // 8)))):
         s_, p_ = f"S{t}", f"P{t}"
         for e in range(16):
             g0 = base + first(e)
+            if mask:                                       # key offset ko of element e inside the tile; the lane's row sees keys up to %[lim]
+                ko = 32 * t + (e & 3) + 8 * (e >> 2)
+                sl[g0].append(f"v_cmp_le_i32 %[msk], {ko}, %[lim]")
+                sl[g0].append(f"v_cndmask_b32 {R(s_, e)}, %[ninf], {R(s_, e)}, %[msk]")
             sl[g0].append(f"v_fma_f32 {R(s_, e)}, {R(s_, e)}, %[sc], -%[l2]")
             sl[g0 + 1].append(f"v_exp_f32 {R(s_, e)}, {R(s_, e)}")
             sl[g0 + 2].append(f"v_mul_f32 {R(s_, e)}, {R(s_, e)}, {R(p_, e)}")
@@ -72,11 +76,17 @@ def ew_slots():
     return sl
 
 
-def body(par):
+def body(par, mask=False):
+    """one tile.  mask: a diagonal tile of the wave — S becomes -inf where the key lies behind the lane's row (two VALU per element in front of its scale /
+    subtract; the compare result in an SGPR pair: vcc carries the tile's "tile u + 1 exists" flag for the LDS-DMA pieces)"""
     o = []
     a = o.append
-    a(f"; ---- tile of stage {par}")
-    ew = ew_slots()
+    a(f"; ---- tile of stage {par}" + (" (masked)" if mask else ""))
+    ew = ew_slots(mask)
+    tag = f"dq_{'m' if mask else 'b'}{par}"
+    a("s_add_u32 %[ts], %[u], 1")                          # the block's last tile requests nothing: vcc = (u + 1 < nu), every request branches on it
+    a("s_cmp_lt_i32 %[ts], %[nu]")
+    a("s_cselect_b64 vcc, -1, 0")
     dma = []                                               # (m0 immediate, source operand, descriptor, scalar offset) of the six pieces of tile u + 1 -> stage par ^ 1
     for img, (src, rs, so) in enumerate((("ks", "krs", "koff"), ("vs", "vrs", "voff"), ("ts", "krs", "koff"))):
         for i in range(2):
@@ -113,7 +123,9 @@ def body(par):
         if g % 2 == 0:
             o.extend(post)
         if g < len(dma) and "nodma" not in ABL:
+            a(f"s_cbranch_vccz {tag}nd{g}%=")
             a(f"buffer_load_dwordx4 {dma[g][1]}, {dma[g][2]}, {dma[g][3]} offen lds")
+            a(f"{tag}nd{g}%=:")
         if "novalu" not in ABL:
             o.extend(ew[g])
     a("s_waitcnt vmcnt(6) lgkmcnt(0)" if ABL_NOWAIT else "s_waitcnt vmcnt(0) lgkmcnt(0)")
@@ -122,8 +134,14 @@ def body(par):
     a("s_add_u32 %[u], %[u], 1")
     a("s_add_u32 %[koff], %[koff], %[kstr]")
     a("s_add_u32 %[voff], %[voff], %[vstr]")
-    a("s_cmp_ge_i32 %[u], %[uend]")
-    a("s_cbranch_scc1 dq_exit%=")
+    if mask:
+        a("v_subrev_u32 %[lim], 64, %[lim]")               # the next tile's keys are 64 further on
+        a("s_cmp_ge_i32 %[u], %[mend]")
+        a("s_cbranch_scc1 dq_exit%=")
+        a(f"s_branch dq_m{par ^ 1}%=")
+    else:
+        a("s_cmp_ge_i32 %[u], %[uend]")
+        a(f"s_cbranch_scc1 dq_d{par ^ 1}%=")               # the unmasked range ends here: on to the masked tiles (or out)
     return o
 
 
@@ -136,11 +154,23 @@ def build(dtype):
         lines.extend(parse_block(op, sym))
     for s in range(1, DS):
         lines.append(f"v_xor_b32 {KADDR[s]}, {s << 5}, %[kaddr]")
-    lines.append("dq_loop%=:")
+    a = lines.append
+    a("v_mov_b32 %[ninf], 0xff800000")
+    a("s_cmp_ge_i32 %[u], %[uend]")                        # (entered at tile 0: no unmasked tile at all -> the masked ones)
+    a("s_cbranch_scc1 dq_d0%=")
+    a("dq_loop%=:")
     lines.extend(body(0))
     lines.extend(body(1))
-    lines.append("s_branch dq_loop%=")
-    lines.append("dq_exit%=:")
+    a("s_branch dq_loop%=")
+    for par in (0, 1):                                     # behind the unmasked range: masked tiles while u < mend, alternating stages
+        a(f"dq_d{par}%=:")
+        a("s_cmp_ge_i32 %[u], %[mend]")
+        a("s_cbranch_scc1 dq_exit%=")
+        a(f"s_branch dq_m{par}%=")
+    for par in (0, 1):
+        a(f"dq_m{par}%=:")
+        lines.extend(body(par, mask=True))
+    a("dq_exit%=:")
     return lines, sum(1 for l in body(0) if not l.startswith(";"))
 
 
