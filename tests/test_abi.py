@@ -597,13 +597,15 @@ def test_fp32_tensors_name_the_fix_on_the_16_bit_only_entries():
 
 
 def test_generated_tile_loops_are_in_sync_with_their_generators():
-    """csrc/tfa_fwd_il_asm_loop.inc and tfa_fwd_x4_asm_loop.inc are GENERATED (tools/gen_il_asm_loop.py, gen_x4_asm_loop.py): the committed text must be what
+    """csrc/tfa_fwd_il_asm_loop.inc, tfa_fwd_x4_asm_loop.inc and the backward's tfa_bwd_dq_asm_loop.inc / tfa_bwd_kv_asm_loop.inc are GENERATED (tools/gen_il_asm_loop.py,
+    gen_x4_asm_loop.py, gen_bwd_dq_asm_loop.py, gen_bwd_kv_asm_loop.py): the committed text must be what
     the committed generators emit with their default knobs — an edit to either side without the other fails here, before it can reach a GPU."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if not k.startswith("TFA_GEN_")}
-    for gen, inc in (("gen_il_asm_loop.py", "tfa_fwd_il_asm_loop.inc"), ("gen_x4_asm_loop.py", "tfa_fwd_x4_asm_loop.inc")):
+    for gen, inc in (("gen_il_asm_loop.py", "tfa_fwd_il_asm_loop.inc"), ("gen_x4_asm_loop.py", "tfa_fwd_x4_asm_loop.inc"),
+                     ("gen_bwd_dq_asm_loop.py", "tfa_bwd_dq_asm_loop.inc"), ("gen_bwd_kv_asm_loop.py", "tfa_bwd_kv_asm_loop.inc")):
         out = subprocess.run([sys.executable, os.path.join(root, "tools", gen)], stdout=subprocess.PIPE, text=True, check=True, env=env).stdout
         have = open(os.path.join(root, "tiny-flash-attention_amd", "csrc", inc)).read()
         assert out == have, f"{inc} is stale: re-run tools/{gen}"
@@ -646,6 +648,40 @@ def test_generated_bodies_have_the_instruction_mix_the_docs_quote():
     assert mix(g.body(0, "t"))["mfma"] == 16 and mix(g.body(0, "t"))["valu"] == 115
 
 
+def test_backward_bodies_have_the_instruction_mix_the_docs_quote():
+    """Round 6, the backward's two launches: a dQ tile is 48 MFMAs, 64 fragment reads, 6 LDS-DMA pieces and 80 + 32 VALU (scale/subtract, exp2, product, pack: 3.5 per
+    score — dP starts at -delta, no subtraction); its masked body adds two VALU per score.  A dK/dV tile is 32 MFMAs per role: role 0 16 x (scale, subtract, exp2) + 8
+    packs per half and the four P stores, role 1 16 x (subtract, unpack, product) + 8 packs and the four P loads; both read the tile's statistics as eight b128."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", name + ".py"))
+        g = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(g)
+        return g
+
+    def mix(lines):
+        ins = [l for l in lines if not (l.startswith(";") or l.startswith(".") or l.endswith(":"))]
+        n = lambda pat: sum(1 for l in ins if re.match(pat, l))
+        return {"mfma": n(r"v_mfma"), "valu": n(r"v_(?!mfma)"), "exp": n(r"v_exp"), "rd": n(r"ds_read"), "wr": n(r"ds_write"), "dma": n(r"buffer_load_dwordx4"), "bar": n(r"s_barrier")}
+
+    dq = load("gen_bwd_dq_asm_loop")
+    dq.build("bf16")
+    m, mm = mix(dq.body(0)), mix(dq.body(0, mask=True))
+    assert m == {"mfma": 48, "valu": 112, "exp": 32, "rd": 64, "wr": 0, "dma": 6, "bar": 1}, m
+    assert mm["valu"] - m["valu"] == 64 + 1 and mm["mfma"] == 48, mm             # 32 scores x (v_cmp + v_cndmask) + the limit's step to the next tile
+    kv = load("gen_bwd_kv_asm_loop")
+    kv.build("bf16")
+    r0, r1, r0m = mix(kv.body(0, 0)), mix(kv.body(1, 0)), mix(kv.body(0, 0, mask=True))
+    assert r0["mfma"] == 32 and r0["valu"] == 112 + 3 and r0["exp"] == 32 and r0["rd"] == 48 + 8 and r0["wr"] == 4 and r0["dma"] == 4, r0   # (+ 3: lane * 4 for the statistics request)
+    assert r1["mfma"] == 32 and r1["valu"] == 112 and r1["exp"] == 0 and r1["rd"] == 48 + 8 + 4 and r1["wr"] == 0 and r1["dma"] == 4, r1
+    assert r0m["valu"] - r0["valu"] == 64 + 1, r0m
+    kv.build("f16")                                        # fp16: the upper half of a P dword takes a shift in front of its conversion
+    assert mix(kv.body(1, 0))["valu"] == 112 + 16
+
+
 def test_library_carries_the_hand_scheduled_loops():
     """The product library must contain the generated steady-state loops (their asm labels survive as local symbols of the code objects): a build with
     -DTFA_IL_USE_ASMLOOP=0 / -DTFA_X4_USE_ASMLOOP=0 — the A/B arms — is not what ships."""
@@ -653,7 +689,9 @@ def test_library_carries_the_hand_scheduled_loops():
     # one label per kernel that carries a loop: the lazy-reference loop in 8 units x (il8, il4, key split, key split paired) x two output types, the exact loop in
     # the 128-wide causal / non-causal units of both types, the 256-wide loop in 32 units
     # (round 6: the statement carries the bodies behind the loop — dispatch, masked, half and last-tile bodies — and, in the bf16 units, the max-free texts' exits)
-    for label, least in ((b"il_loop", 64), (b"ix_exit", 8), (b"x4_loop", 32), (b"il_mh0", 64), (b"il_lh1", 64), (b"il_d1", 64), (b"il_x0", 32), (b"ix_l0", 8)):
+    # (late round 6: the backward's dQ launch — 128 wide, causal x gradient type x dtype = 8 kernels — and the fused dK/dV launch, 8 kernels, with their masked bodies)
+    for label, least in ((b"il_loop", 64), (b"ix_exit", 8), (b"x4_loop", 32), (b"il_mh0", 64), (b"il_lh1", 64), (b"il_d1", 64), (b"il_x0", 32), (b"ix_l0", 8),
+                         (b"dq_loop", 8), (b"dq_m1", 8), (b"kv_r0m2", 8), (b"kv_r1b2", 8), (b"kv_exit", 8)):
         assert raw.count(label) >= least, f"{raw.count(label)} {label.decode()} labels in libtfa_hip.so, expected {least}: hand-scheduled loops are missing from this build"
     # ... and the windowed instantiations that (b,h) slices of 2 GiB and more run (round 5: the 256-wide forward kernel, VF | VF_X4_WINDOWED, and the 256-wide
     # backward kernel with BIG = true in all three modes)
