@@ -94,6 +94,12 @@ BWD_SHAPES = [
     (torch.float16, 1, 2, 2, 333, 200, 64, False),       # Nq > Nk
     (torch.float16, 1, 3, 3, 700, 100, 128, True),       # causal with 600 query rows that see no key
     (torch.bfloat16, 2, 2, 2, 1024, 1024, 128, True),
+    # the hand-scheduled statements of both launches (128 wide; tools/gen_bwd_dq_asm_loop.py, gen_bwd_kv_asm_loop.py): whole tiles, several per block, the diagonal's masked
+    # bodies, per streamed head under GQA / MQA, both 16-bit types, bottom-right causal with Nq != Nk
+    (torch.bfloat16, 1, 4, 2, 1024, 1024, 128, True),
+    (torch.float16, 1, 4, 1, 768, 1280, 128, False),
+    (torch.float16, 1, 2, 2, 1024, 896, 128, True),
+    (torch.bfloat16, 1, 6, 2, 640, 1152, 128, True),
     (torch.bfloat16, 1, 1, 1, 64, 64, 128, False),       # a single tile
     (torch.float16, 1, 2, 1, 1, 500, 64, True),          # single query row (decode-like)
     (torch.bfloat16, 1, 1, 1, 77, 65, 64, False),

@@ -303,33 +303,40 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
   }
   int st_next = 1;                                   // stage of tile it+1
   int st_mine = role ? NSTAGE - 1 : 0;               // stage of this wave's tile (role 1: tile it-1)
-  // ---- the hand-scheduled iterations a_it0 .. a_it1 - 1 of this wave: its tile (role 0: it, role 1: it - 1) needs no mask, tile it + 1 exists and lies wholly
-  //      inside the query rows (its LDS-DMA pieces take the tile's byte offset as the SCALAR offset, outside the descriptor's bounds check), one streamed head
-  //      (G = 1), every key of the block inside the sequence (the -inf start of a padded key's S is the compiler-scheduled body's)
-  int a_it0 = 0, a_it1 = 0, a_um = 0;
+  // ---- the hand-scheduled iterations a_it0 .. a_it1 - 1 of this wave, per streamed head: from its first active tile (role 0: it, masked bodies for the diagonal
+  //      tiles below a_um; role 1: it - 1, P arrives masked) to the head's last request-free point — every tile requested from inside the statement belongs to the
+  //      SAME head (the descriptors change at a head's end: the compiler-scheduled iterations do that) and lies wholly inside the query rows (the LDS-DMA pieces take
+  //      the tile's byte offset as the SCALAR offset, outside the descriptor's bounds check).  Every key of the block inside the sequence (the -inf start of a
+  //      padded key's S is the compiler-scheduled body's).
+  int a_it0 = 0, a_it1 = 0, a_um = 0, a_head = 0;
+  int a_ua = 0, a_uml = 0;                           // the wave's first active tile / first tile without a mask, inside a head's tile sequence
+  const bool a_ok = ASMKV && r0 + BMK <= p.Nk;
+  auto a_range = [&](int h) {                        // the range of streamed head h
+    const int base = h * ntl;
+    a_it0 = base + a_ua + role;
+    a_um = base + a_uml;
+    if (p.Nq % BN != 0) { int l = ntl - 1; const int whole = p.Nq / BN - t_begin - 1; l = whole < l ? whole : l; a_it1 = base + l; }
+    else a_it1 = h == G - 1 ? nu + role : base + ntl - 1;
+    a_it0 = __builtin_amdgcn_readfirstlane(a_it0);
+    a_it1 = __builtin_amdgcn_readfirstlane(a_it1);
+    a_um = __builtin_amdgcn_readfirstlane(a_um);
+  };
   if constexpr (ASMKV) {
-    if (G == 1 && r0 + BMK <= p.Nk) {
-      int ua = 0, um = 0;                              // the wave's first active tile / first tile without a mask (positions in the block's tile sequence)
+    if (a_ok) {
       if (CAUSAL) {
         const int v = wave_row0 - shift;               // the first query that sees the wave's first key
         const int ja = v > 0 ? v / BN : 0;             // first tile with a query that sees a key of the wave
         const int jm = v + 31 > 0 ? (v + 31 + BN - 1) / BN : 0;   // first tile whose 64 queries all see the wave's 32 keys
-        ua = ja > t_begin ? ja - t_begin : 0;
-        um = jm > t_begin ? jm - t_begin : 0;
+        a_ua = ja > t_begin ? ja - t_begin : 0;
+        a_uml = jm > t_begin ? jm - t_begin : 0;
       }
-      a_it0 = ua + role;                               // role 0: masked tiles too (its masked bodies); role 1 needs none (P arrives masked)
-      a_um = um;
-      // every tile requested from inside the statement lies wholly inside the query rows: all of them when the last tile is whole, else up to the last but one
-      if (p.Nq % BN == 0) a_it1 = nu + role;
-      else { a_it1 = nu - 1; const int whole = p.Nq / BN - t_begin - 1; a_it1 = whole < a_it1 ? whole : a_it1; }
-    }
-    a_it0 = __builtin_amdgcn_readfirstlane(a_it0);
-    a_it1 = __builtin_amdgcn_readfirstlane(a_it1);
-    a_um = __builtin_amdgcn_readfirstlane(a_um);
+      a_range(0);
+    } else a_it0 = -1;                                 // (never reached)
   }
 #pragma nounroll
   for (int it = 0; it <= nu; ++it) {
     if constexpr (ASMKV) {
+      if (it == a_it0 && a_it1 <= a_it0) { if (++a_head < G) a_range(a_head); else a_it0 = -1; }   // (nothing of this head for the statement)
       if (it == a_it0 && a_it1 > a_it0) {
         f32x16 ax0, ax1, ast;
         u32x4 af0, af1, af2, af3, aka, at1, at2, app0, app1, app2, app3, atm0;
@@ -357,8 +364,13 @@ __global__ __launch_bounds__(KG * 128, KG == 6 ? 3 : 2) void bwd_kv_kernel(const
         else { TFA_BWD_KV_ASM_STMT(TFA_BWD_KV_ASM_LOOP_F16); }
         const int n = a_it - it;                       // iterations done: the streams' positions and the stage rotation move with them
         jt_d += n; jt_c += n;
+        if (jt_d >= t_end) {                           // the statement requested the head's last tile: on to the next head's descriptors (dma_next's own step)
+          jt_d = t_begin;
+          if (++g_d < G) { q_rs = head_rsrc(p.q, g_d); do_rs = head_rsrc(p.dout, g_d); lse_rs = stat_rsrc(p.lse, g_d); dl_rs = stat_rsrc(p.delta, g_d); }
+        }
         st_next = (st_next + n) % NSTAGE; st_mine = (st_mine + n) % NSTAGE;
         it = a_it;
+        if (++a_head < G) a_range(a_head); else a_it0 = -1;
         if (it > nu) break;                            // (role 1 ran the last iteration inside the statement)
       }
     }

@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT)
 from tiny_flash_attention_amd import _lib, ops
 CFG = {"cfg3": (4, 32, 4096, 128, torch.bfloat16, True), "cfg3nc": (4, 32, 4096, 128, torch.bfloat16, False),
        "cfg4": (1, 16, 16384, 128, torch.bfloat16, False), "cfg5": (8, 32, 4096, 128, torch.bfloat16, True),
-       "d64": (4, 32, 4096, 64, torch.float16, False), "d64c": (4, 32, 4096, 64, torch.float16, True)}
+       "d64": (4, 32, 4096, 64, torch.float16, False), "d64c": (4, 32, 4096, 64, torch.float16, True),
+       "gqa": (4, 32, 4096, 128, torch.bfloat16, True, 8), "gqanc": (4, 32, 4096, 128, torch.bfloat16, False, 8), "f16c": (4, 32, 4096, 128, torch.float16, True)}
 ap = argparse.ArgumentParser()
 ap.add_argument("libs", nargs=2)
 ap.add_argument("--variant", type=int, default=28)
@@ -30,9 +31,10 @@ for path in a.libs:
 va = a.variant
 vb = a.variant if a.variant_b is None else a.variant_b
 for cfg in a.cfgs.split(","):
-    B, H, N, D, dt, causal = CFG[cfg]
-    mk = lambda: torch.empty((B, H, N, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(dt)
-    q, k, v = mk(), mk(), mk()
+    B, H, N, D, dt, causal = CFG[cfg][:6]
+    Hk = CFG[cfg][6] if len(CFG[cfg]) > 6 else H          # (a seventh entry: K/V heads — GQA)
+    mk = lambda h=H: torch.empty((B, h, N, D), dtype=torch.float32, device=dev).normal_(0, 0.5).to(dt)
+    q, k, v = mk(), mk(Hk), mk(Hk)
     out = torch.empty_like(q); lse = torch.empty((B, H, N), dtype=torch.float32, device=dev)
     p = ops.make_params(q, k, v, out, lse, causal, 1 / math.sqrt(D))
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
