@@ -357,7 +357,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void bwd_kernel(const BAr
   // dQ launch, two waves per SIMD: dP starts at -delta of the lane's row instead of 0 — sixteen registers that never change, read as the C operand of each
   // half's first dP MFMA where it read the inline constant 0 — and dS = P o dP' needs no subtraction per element (32 VALU per tile; every path of the
   // launch — the hand-scheduled tiles, the compiler-scheduled ones, the windowed instantiation — forms the same sums in the same order)
-  constexpr bool DQ_CINIT = MODE == BWD_DQ && NW == 8;
+  constexpr bool DQ_CINIT = MODE == BWD_DQ && NW == 8 && D == 128;   // (64 wide: the sixteen registers would cost the kernel its second workgroup per CU — 142 instead of 126)
   f32x16 dinit;
   if constexpr (DQ_CINIT) {
 #pragma unroll
