@@ -1,6 +1,8 @@
 """Randomised cross-check of tfa_bwd against fp32 autograd on the device: random B, H, Hk, Nq, Nk, D (multiples of 8 up to
 256), dtype, causal, layout.  Bar per gradient: max|d| <= 2e-2 * max|ref| + 1e-3 (16-bit P, dS and outputs; the per-element
-bounds are tests/test_bwd_gpu.py's job).  usage: python tools/fuzz_bwd.py [--n 150] [--seed 0]"""
+bounds are tests/test_bwd_gpu.py's job).  usage: python tools/fuzz_bwd.py [--n 150] [--seed 0] [--focus asm]
+--focus asm: the shapes that run the hand-scheduled statements of both launches (128 wide, the default form): several whole tiles per block, lengths that are
+and are not multiples of 64 / 128 / 256, Nq != Nk under the bottom-right causal mask, GQA / MQA, both 16-bit types, both layouts."""
 import argparse, math, os, random, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +12,7 @@ from tiny_flash_attention_amd import _lib, ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=150)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--focus", default="", choices=["", "asm"])
 a = ap.parse_args()
 rng = random.Random(a.seed)
 dev = torch.device("cuda:0")
@@ -26,6 +29,14 @@ for it in range(a.n):
         Nq = Nk = max(1, rng.choice([64, 128, 256, 512, 1024]) + rng.choice([0, 0, 1, -1, 17, -37]))
     else:
         Nq, Nk = rng.randint(1, 900), rng.randint(1, 1500)
+    if a.focus == "asm":
+        D = rng.choice([128, 128, 128, 104, 120])
+        Hk = rng.choice([1, 2, 3])
+        H = Hk * rng.choice([1, 2, 4])
+        B = rng.choice([1, 2])
+        base = rng.choice([320, 512, 640, 768, 1024, 1280, 1536, 2048])
+        Nq = base + rng.choice([0, 0, 0, 64, -64, 128, 1, -1, 37])
+        Nk = Nq if rng.random() < 0.5 else max(64, Nq + rng.choice([-256, -64, 64, 192, 448, 1, -37]))
     layout = rng.choice(["bhnd", "bnhd"])
     shp = (lambda n, h: (B, h, n, D)) if layout == "bhnd" else (lambda n, h: (B, n, h, D))
     mk = lambda n, h: torch.empty(shp(n, h), dtype=torch.float32, device=dev).normal_(0.0, 0.5, generator=g).to(dt)
@@ -34,6 +45,8 @@ for it in range(a.n):
     out, lse = ops.flash_attn_fwd(q, k, v, causal, sc, layout=layout)
     mode = rng.choice(["default", "default", "workspace", "split", "windowed"])     # tfa_bwd's three forms (tests/test_bwd_gpu.py: MODES) + the >= 2 GiB instantiations, forced
     if mode == "windowed" and D > 128:
+        mode = "default"
+    if a.focus == "asm" and rng.random() < 0.8:
         mode = "default"
     f32 = rng.random() < 0.25                          # fp32 gradients
     _lib.debug_bwd_split({"split": 1, "windowed": 2}.get(mode, 0))
