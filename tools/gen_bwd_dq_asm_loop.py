@@ -13,7 +13,10 @@ A tile = 64 keys against the wave's 32 resident query rows, two halves t of 32 k
 Order in a tile: GI(0) | GI(1) with EW(0) in its shadow | GII(0) with most of EW(1) | GII(1) with the rest — every VALU instruction has an MFMA in front of it.
 Fragments travel as in the forward loop: four 4-register buffers in rotation, requested in pairs two MFMAs ahead, one s_waitcnt per pair.  The tile's first six
 MFMA slots carry the wave's six LDS-DMA pieces of tile u + 1 (K, V and transposed-K images of the other stage); one s_waitcnt vmcnt(0) + s_barrier per tile, the
-protocol of the compiler-scheduled loop around it (tfa_bwd_kernel.h), so a wave may leave for that loop — masked / ragged tiles, the last tile — at any tile.
+protocol of the compiler-scheduled loop around it (tfa_bwd_kernel.h), so a wave may leave for that loop — ragged and inactive tiles — at any tile.
+Behind the unmasked tiles (u < %[uend]) the statement runs the wave's diagonal tiles (u < %[mend]) in MASKED bodies: S becomes -inf where the key lies behind the
+lane's row, two VALU per score in front of its scale / subtract (the compare result in an SGPR pair).  Every request is predicated on "tile u + 1 exists"
+(vcc, set at the head of a tile), so the block's last tile runs inside as well.
 
 LDS (bytes; the compiler-scheduled loop of this instantiation uses the same map): row-major images at (2 stage + image) * 0x4000 (image 0 K, 1 V) — every
 ds_read_b128 offset fits the 16-bit immediate —, transposed K images at 0x10000 + stage * 0x4000 (the address operand `vat` carries the 0x10000).
