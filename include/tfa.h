@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define TFA_VERSION 110 /* 0.1.10: bf16 on the default kernels rounds P against the first key tile's row maximum (max-free tile loop; tfa_fwd_rounding_rule says which rule a call runs), the tile bodies behind the hand-scheduled loop are generated too, tfa_debug_mfma_ceiling returns TFA_ERR_SHAPE for bad sizes; 0.1.9: (b,h) slices of 2 GiB and more at head dims above 128 (windowed instantiations of the 256-wide forward and backward kernels; TFA_ERR_STRIDE before), tfa_debug_mfma_ceiling; 0.1.8: TFA_FWD_EXACT_MAX runs the il8 kernel's exact-max instantiation (variant 38) on grids that fill the chip; 0.1.7: tfa_bwd computes delta inside its dQ launch (tfa_debug_bwd_split bit 3 restores the separate launch), tfa_debug_set_trace is served by traced twins of the main kernels; 0.1.6: + fp32 q,k,v (TFA_F32 input: the correctness path behind the reference's fp32 fixtures), variant numbers are ids (tfa_variant_available), tfa_bwd_workspace_bytes is 0 wherever the workspace would be ignored; 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
+#define TFA_VERSION 111 /* 0.1.11: tfa_bwd at head dims up to 128 runs hand-scheduled tile loops in both launches; the dQ launch accumulates dP from -delta (gradient bits differ from 0.1.10, inside the same bounds); no interface change.  0.1.10: bf16 on the default kernels rounds P against the first key tile's row maximum (max-free tile loop; tfa_fwd_rounding_rule says which rule a call runs), the tile bodies behind the hand-scheduled loop are generated too, tfa_debug_mfma_ceiling returns TFA_ERR_SHAPE for bad sizes; 0.1.9: (b,h) slices of 2 GiB and more at head dims above 128 (windowed instantiations of the 256-wide forward and backward kernels; TFA_ERR_STRIDE before), tfa_debug_mfma_ceiling; 0.1.8: TFA_FWD_EXACT_MAX runs the il8 kernel's exact-max instantiation (variant 38) on grids that fill the chip; 0.1.7: tfa_bwd computes delta inside its dQ launch (tfa_debug_bwd_split bit 3 restores the separate launch), tfa_debug_set_trace is served by traced twins of the main kernels; 0.1.6: + fp32 q,k,v (TFA_F32 input: the correctness path behind the reference's fp32 fixtures), variant numbers are ids (tfa_variant_available), tfa_bwd_workspace_bytes is 0 wherever the workspace would be ignored; 0.1.5: + tfa_fwd_params::flags (TFA_FWD_EXACT_MAX), split-KV for head dims up to 256; 0.1.4: + tfa_fwd_suggest_splits, key-split kernels for small grids, split-KV / backward head dims multiples of 8; 0.1.3: forward head dims = every multiple of 8 up to 256; tfa_debug_set_flags; 0.1.2: + tfa_variant_available; debug knobs are per thread; 0.1.1: split-KV, tfa_merge, tfa_bwd */
 
 /* element types */
 enum tfa_dtype { TFA_F16 = 0, TFA_BF16 = 1,

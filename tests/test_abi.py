@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"include/tfa.h declares {n} but libtfa_hip.so does not export it"
     assert sorted(_lib.SYMBOLS) == names
-    assert L.tfa_version() == 110
+    assert L.tfa_version() == 111
 
 
 def _params(B=2, H=4, Hk=4, Nq=128, Nk=128, D=128, dtype=_lib.TFA_BF16, out_dtype=None, scale=0.1, base=0x10000):
