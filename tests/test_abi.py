@@ -518,6 +518,40 @@ def test_assembly_audit_tools_flag_what_they_exist_for(tmp_path):
     assert subprocess.run(["bash", ag, str(good)], capture_output=True, text=True).stdout.strip() == ""
 
 
+def test_loop_audit_models_the_in_order_lds_queue():
+    """tools/audit_il_asm_loop.py: check() walks a disassembled statement.  Three things it exists for, on synthetic sequences: an MFMA that reads a fragment still in
+    flight is reported; a store between two reads holds its place in the queue lgkmcnt counts (the backward's P hand-off: without it every later wait looks one short);
+    a pack that writes an MFMA operand one instruction in front of the MFMA is reported."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("audit_loop", os.path.join(ROOT, "tools", "audit_il_asm_loop.py"))
+    au = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(au)
+    P = lambda txt: [au.parse("\t" + l) for l in txt.strip().splitlines()]
+    early = P("""
+ds_read_b128 v[10:13], v1
+ds_read_b128 v[14:17], v1 offset:64
+s_waitcnt lgkmcnt(1)
+v_mfma_f32_32x32x16_bf16 v[20:35], v[14:17], v[40:43], 0
+""")
+    assert any("[1]" in f for f in au.check(early)), au.check(early)
+    with_store = P("""
+ds_read_b128 v[10:13], v1
+ds_write_b128 v2, v[60:63]
+ds_read_b128 v[14:17], v1 offset:64
+s_waitcnt lgkmcnt(2)
+v_mfma_f32_32x32x16_bf16 v[20:35], v[10:13], v[40:43], 0
+s_waitcnt lgkmcnt(0)
+v_mfma_f32_32x32x16_bf16 v[20:35], v[14:17], v[40:43], v[20:35]
+""")
+    assert au.check(with_store) == [], au.check(with_store)
+    short = P("""
+v_cvt_pk_bf16_f32 v40, v50, v51
+s_nop 0
+v_mfma_f32_32x32x16_bf16 v[20:35], v[10:13], v[40:43], 0
+""")
+    assert any("[2]" in f for f in au.check(short)), au.check(short)
+
+
 def test_work_item_decode_matches_plain_divisions():
     """the il kernels decode (b, h, k/v head, work item) from the workgroup id with host-computed magic-number divisions in one branch-free
     form (tfa_launch.h: fill_decode); tfa_debug_decode evaluates exactly that on the host.  Against the three dispatch orders written with
