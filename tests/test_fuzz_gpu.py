@@ -19,6 +19,9 @@ def test_fuzz_forward_against_device_fp32(args):
     assert " ok; kernels used" in r.stdout
 
 
-def test_fuzz_backward_against_device_autograd():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_bwd.py"), "--n", "120", "--seed", "9"], capture_output=True, text=True, timeout=900)
+@pytest.mark.parametrize("args", [["--n", "120", "--seed", "9"],
+                                  # the shapes that run the hand-scheduled statements of both backward launches: 128 wide, several whole tiles, GQA / MQA, Nq != Nk, ragged lengths
+                                  ["--n", "120", "--seed", "10", "--focus", "asm"]])
+def test_fuzz_backward_against_device_autograd(args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_bwd.py")] + args, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, "\n".join((r.stdout + r.stderr).splitlines()[-12:])
